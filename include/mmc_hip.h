@@ -1,0 +1,227 @@
+/*
+ * mmc_hip.h -- C ABI of libmmc_hip.so: the MI355X (gfx950) implementation of the per-move energy
+ * hot path of BradenDKelly/MetropolisMonteCarlo.
+ *
+ * The reference has no FFI layer: its boundary is the set of Julia generic functions that
+ * `Loop()` (Ewald/main.jl:460-696) and `potential()` (Ewald/energy.jl:946-1032) call.  Each entry
+ * point below names the reference method it replaces (file:line into /root/reference).  The Julia
+ * methods of the same names that `ccall` these symbols are in
+ * metropolismontecarlo_amd/julia/MMCHip.jl and INTEGRATION.md; the Python mirror used by the
+ * tests is metropolismontecarlo_amd/api.py.
+ *
+ * Conventions (what a `ccall` passes):
+ *   - every array is a Julia Vector of bits types, borrowed for the duration of the call only:
+ *       Vector{SVector{3,Float64}}  -> const double*  (3 doubles per element, x y z)
+ *       Vector{Float64}             -> const double*
+ *       Vector{Int64}               -> const int64_t* (atom ranges / types are 1-BASED, inclusive)
+ *       Vector{SVector{3,Int32}}    -> int32_t*       (3 per element)
+ *       Vector{ComplexF64}          -> double*        (re, im interleaved)
+ *       Matrix{Float64}             -> const double*  (column-major n_types x n_types)
+ *   - molecule indices (`i`, `chosenOne`) are 1-BASED as in the reference;
+ *   - every function returns an int32 status (MMC_OK == 0); results come back through
+ *     out-pointers; the library never calls exit() (the reference does, energy.jl:426-428);
+ *   - a reference `@assert` becomes MMC_ERR_ASSERT; mmc_last_error() has the text;
+ *   - one context (or batch) is not thread-safe, like the reference's mutable EWALD; different
+ *     contexts may be driven from different threads and run on different HIP streams.
+ * All arithmetic is fp64.  Energies are in K, lengths in Angstrom, charges in e.
+ */
+#ifndef MMC_HIP_H
+#define MMC_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    MMC_OK = 0,
+    MMC_ERR_ARG = 1,      /* null pointer, bad size, index out of range */
+    MMC_ERR_ASSERT = 2,   /* a reference @assert would have thrown */
+    MMC_ERR_HIP = 3,      /* a HIP runtime call failed (no device, OOM, launch failure) */
+    MMC_ERR_STATE = 4,    /* call order: e.g. RecipMove before PrepareEwaldVariables */
+    MMC_ERR_UNSUPPORTED = 5
+};
+
+typedef struct mmc_ctx mmc_ctx;     /* one system (one Markov chain) resident on one GPU */
+typedef struct mmc_batch mmc_batch; /* R independent replicas of one system on one GPU   */
+
+/* Totals written by the total-energy drivers: the fields of `Properties`
+ * (Ewald/auxillary.jl:37-45) that potential() fills, plus the four terms it println()s. */
+typedef struct {
+    double energy, virial, coulomb;
+    double lj, real, recip, self;
+    int32_t n_overlap; /* molecules for which EwaldReal returned (0.0, true) */
+    int32_t _pad;
+} mmc_totals;
+
+const char *mmc_last_error(void); /* thread-local text of the last non-OK status */
+const char *mmc_version(void);
+int32_t mmc_device_count(int32_t *count);
+
+/* ---- context ------------------------------------------------------------------------------- */
+/* `hip_stream`: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream), or
+ * NULL to let the context own a non-blocking stream. */
+int32_t mmc_ctx_create(int32_t device, void *hip_stream, mmc_ctx **out);
+int32_t mmc_ctx_destroy(mmc_ctx *ctx);
+int32_t mmc_ctx_synchronize(mmc_ctx *ctx);
+
+/* Mirror moa/soa/vdwTable on the device.  Replaces nothing in the reference -- it is the price of
+ * a device: the fields are exactly those LJ_poly_dU / EwaldReal read (Ewald/energy.jl:216-229,
+ * Ewald/ewalds.jl:305-308): moa.COM, moa.firstAtom, moa.lastAtom, soa.coords, soa.atype,
+ * soa.charge, vdwTable.eps_ij, vdwTable.sig_ij (Ewald/structs.jl:337-347), box. */
+int32_t mmc_upload_system(mmc_ctx *ctx, int64_t n_mol, int64_t n_atoms, const double *com,
+                          const int64_t *first_atom, const int64_t *last_atom,
+                          const double *coords, const int64_t *atype, const double *charge,
+                          int64_t n_types, const double *eps, const double *sig, double box);
+/* Loop() writes the moved molecule into moa.COM[i] / soa.coords[first:last] before it calls the
+ * energy functions (Ewald/main.jl:527,552) and restores them on rejection (:623-624); this is the
+ * device-side counterpart of those two assignments.  `atoms`: 3*(last-first+1) doubles. */
+int32_t mmc_set_molecule(mmc_ctx *ctx, int64_t i, const double *com, const double *atoms);
+/* Re-send every centre of mass and atom position (same topology): the whole-array form of the
+ * assignments above, for callers that changed more than one molecule on the host. */
+int32_t mmc_update_system(mmc_ctx *ctx, const double *com, const double *coords);
+int32_t mmc_download_system(mmc_ctx *ctx, double *com, double *coords);
+
+/* PrepareEwaldVariables(ewald, boxSize)                       Ewald/ewalds.jl:45-103
+ * Builds kxyz/cfac on the device, zeroes sumQExpOld/New.  k_sq_max != 27 -> MMC_ERR_ASSERT (:49).
+ * `factor` is EWALD.factor (Ewald/constants.jl:24-28). */
+int32_t mmc_prepare_ewald(mmc_ctx *ctx, double kappa, int64_t nk, int64_t k_sq_max, double box,
+                          double factor, int64_t *nkvecs);
+int32_t mmc_get_kvectors(mmc_ctx *ctx, int32_t *kxyz /* [NKVECS][3] */, double *cfac);
+/* EWALD.sumQExpOld / sumQExpNew (Ewald/ewalds.jl:16-17); either pointer may be NULL. */
+int32_t mmc_get_sumqexp(mmc_ctx *ctx, double *sum_old, double *sum_new);
+int32_t mmc_set_sumqexp(mmc_ctx *ctx, const double *sum_old, const double *sum_new);
+
+/* LJ_poly_dU(i, moa, soa, vdwTable, r_cut, box)               Ewald/energy.jl:209-290
+ * (and the legacy LJ_poly_dU(i, system::Requirements)          Ewald/energy.jl:126-206)
+ * -> (4*pot, 24*vir/3). */
+int32_t mmc_lj_poly_du(mmc_ctx *ctx, int64_t i, double r_cut, double *pot, double *vir);
+
+/* EwaldReal(chosenOne, moa, soa, ewald, r_cut, box)           Ewald/ewalds.jl:293-376, ovr = 0.5
+ * EwaldReal(qq_r, qq_q, kappa, box, thisMol_thisAtom, i, sys) Ewald/ewalds.jl:205-289, ovr = 1.0
+ * -> (pot, overlap); pot WITHOUT factor; overlap -> pot = 0.0 (:359-360). */
+int32_t mmc_ewald_real(mmc_ctx *ctx, int64_t i, double r_cut, double ovr, double *pot,
+                       int32_t *overlap);
+
+/* EwaldShort(i, moa, soa, sim_props, ewald, box)              Ewald/ewalds.jl:892-910
+ * -> (e = EwaldReal*factor, e/3, overlap) with r_cut = sim_props.qq_rcut. */
+int32_t mmc_ewald_short(mmc_ctx *ctx, int64_t i, double qq_rcut, double *e, double *v,
+                        int32_t *overlap);
+
+/* CoulombReal(qq_r, qq_q, box, chosenOne, system)             Ewald/energy.jl:618-711
+ * bare Coulomb: COM gate r_cut + (r_cut*0.25+5), ovr = 1, atomic cutoff r2 < r_cut^2;
+ * r_cut != 10.0 -> MMC_ERR_ASSERT (:648). */
+int32_t mmc_coulomb_real(mmc_ctx *ctx, int64_t i, double r_cut, double *pot, int32_t *overlap);
+
+/* RecipLong(ewald, r, qq_q, box)                              Ewald/ewalds.jl:538-604
+ * (legacy RecipLong(system, ewald, r, qq_q)                    Ewald/ewalds.jl:465-534)
+ * Full structure factor of the uploaded atoms; writes BOTH sumQExpOld and sumQExpNew (:600-601);
+ * energy WITHOUT factor (:603). */
+int32_t mmc_recip_long(mmc_ctx *ctx, double *energy);
+
+/* RecipMove(box, ewalds, r_old, r_new, qq_q)                  Ewald/ewalds.jl:718-826
+ * n != 3, k_sq_max != 27 or nk != 5 -> MMC_ERR_ASSERT (:740-743).  sumQExpNew += dS in place
+ * (:805-814); returns energy*factor (:825). */
+int32_t mmc_recip_move(mmc_ctx *ctx, const double *r_old, const double *r_new, const double *q,
+                       int64_t n, double *d_energy);
+
+/* ewald.sumQExpOld = copy(ewald.sumQExpNew)                   Ewald/main.jl:621 */
+int32_t mmc_recip_commit(mmc_ctx *ctx);
+/* ewald.sumQExpNew = copy(ewald.sumQExpOld)                   Ewald/main.jl:628 */
+int32_t mmc_recip_rollback(mmc_ctx *ctx);
+
+/* EwaldSelf(ewald, qq_q)                                      Ewald/ewalds.jl:829-833 (factor in) */
+int32_t mmc_ewald_self(mmc_ctx *ctx, double *self_energy);
+
+/* potential(moa, soa, tot, ewalds, vdwTable, sim_props, "ewald")   Ewald/energy.jl:946-1032
+ * lj_rcut = sim_props.LJ_rcut, qq_rcut = sim_props.qq_rcut.  Takes everything from the context
+ * (the reference reads globals `ewald`, `totProps`, :994 -- identical at its only call site). */
+int32_t mmc_potential_ewald(mmc_ctx *ctx, double lj_rcut, double qq_rcut, mmc_totals *tot);
+/* potential(moa, soa, tot, ewald, vdwTable, sim_props)  ("Wolf")  Ewald/energy.jl:864-943 */
+int32_t mmc_potential_wolf(mmc_ctx *ctx, double lj_rcut, double qq_rcut, mmc_totals *tot);
+
+/* The five hot-path calls of one Loop() iteration in ONE launch   Ewald/main.jl:491-593
+ * (2x LJ_poly_dU, 2x EwaldShort, RecipMove) for molecule i moved to com_new/atoms_new.
+ * d[0] = E_new_LJ - E_old_LJ, d[1] = real new - old (factor in), d[2] = deltaRecip (0 when
+ * overlap, :580-590), d[3] = virial new - old + deltaRecip/3 (:600-601).  The device state is
+ * left OLD; follow with mmc_accept_move (:598-621) or mmc_reject_move (:622-629). */
+int32_t mmc_trial_move(mmc_ctx *ctx, int64_t i, const double *com_new, const double *atoms_new,
+                       double lj_rcut, double qq_rcut, double d[4], int32_t *overlap);
+int32_t mmc_accept_move(mmc_ctx *ctx);
+int32_t mmc_reject_move(mmc_ctx *ctx);
+
+/* ---- replica batch: R independent NVT chains of the same system on one GPU ------------------ */
+typedef struct {
+    int32_t mol;         /* 1-based molecule index of this replica's trial move */
+    int32_t accept_prev; /* 1: the PREVIOUS proposal of this replica was accepted -> commit it
+                            (Ewald/main.jl:598-621) before evaluating; 0: discard it (:622-629) */
+    double com_new[3];   /* moa.COM[i] after the move            (Ewald/main.jl:527) */
+    double atoms_new[9]; /* soa.coords[first:last] after the move (Ewald/main.jl:552) */
+} mmc_move;
+
+typedef struct {
+    double d_lj;    /* partial_new_e - partial_old_e, LJ part     (Ewald/main.jl:491,557) */
+    double d_real;  /* EwaldShort new - old, factor applied       (Ewald/main.jl:501,566) */
+    double d_recip; /* RecipMove, factor applied; 0 when overlap  (Ewald/main.jl:580-590) */
+    double d_vir;   /* virial new - old + d_recip/3               (Ewald/main.jl:600-601) */
+    int32_t overlap;
+    int32_t _pad;
+} mmc_move_result;
+
+/* All replicas start from the given configuration (3 atoms per molecule required: RecipMove's
+ * `@assert n == 3`, Ewald/ewalds.jl:740).  Ewald tables are prepared as mmc_prepare_ewald does;
+ * call mmc_batch_recip_long once before the first mmc_batch_eval. */
+int32_t mmc_batch_create(int32_t device, void *hip_stream, int64_t n_replicas, int64_t n_mol,
+                         const double *com, const double *coords, const int64_t *atype,
+                         const double *charge, int64_t n_types, const double *eps,
+                         const double *sig, double box, double kappa, int64_t nk,
+                         int64_t k_sq_max, double factor, double lj_rcut, double qq_rcut,
+                         mmc_batch **out);
+int32_t mmc_batch_destroy(mmc_batch *b);
+int32_t mmc_batch_set_replica(mmc_batch *b, int64_t r, const double *com, const double *coords);
+int32_t mmc_batch_get_replica(mmc_batch *b, int64_t r, double *com, double *coords,
+                              double *sum_old);
+/* RecipLong for every replica; energies[r] WITHOUT factor. */
+int32_t mmc_batch_recip_long(mmc_batch *b, double *energies);
+/* potential(..., "ewald") for every replica. */
+int32_t mmc_batch_potential_ewald(mmc_batch *b, mmc_totals *tot);
+/* One trial move per replica, one launch: moves[r] -> results[r].  moves[r].accept_prev settles
+ * the replica's previous proposal first.  Synchronous. */
+int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *results);
+/* Workgroups per replica-move used by mmc_batch_eval (1..16; 1 = one workgroup does the whole
+ * move, >1 = the molecule range is split and the last workgroup does the reciprocal part). */
+int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
+/* Settle the last outstanding proposals without evaluating new ones. */
+int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
+
+/* Native host driver: the sequential accept/reject of Loop() (Ewald/main.jl:487-644) for every
+ * replica, in C++ on the host, around mmc_batch_eval's kernel.  Sweeps molecules in order like
+ * the reference (`for i = 1:numbers.molecules`, :490). */
+typedef struct {
+    double temperature;  /* K                                (Ewald/main.jl:62)  */
+    double dr_max;       /* translation box width, Angstrom  (Ewald/main.jl:118) */
+    double dphi_max;     /* max rotation angle, rad          (Ewald/main.jl:73)  */
+    uint64_t seed;       /* replica r draws from stream seed + r */
+    int64_t n_steps;     /* trial moves per replica to run */
+    int32_t n_groups;    /* replica groups pipelined on separate streams (>=1) */
+    int32_t n_parts;     /* workgroups per replica-move (0 = choose) */
+    int32_t time_kernels;/* 1: bracket every launch with HIP events (stats.kernel_ms) */
+    int32_t _pad;
+} mmc_run_params;
+
+typedef struct {
+    int64_t moves, launches;
+    int64_t trans_attempt, trans_accept, rot_attempt, rot_accept, overlaps;
+    double wall_ms;      /* host wall clock over the run */
+    double kernel_ms;    /* sum of HIP-event durations of the move kernel (time_kernels) */
+    double energy_sum;   /* sum over replicas of the running total energy at the end */
+} mmc_run_stats;
+
+/* energies: in/out running total energy per replica (R doubles), as `total.energy` (:599). */
+int32_t mmc_batch_run(mmc_batch *b, const mmc_run_params *p, double *energies,
+                      mmc_run_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

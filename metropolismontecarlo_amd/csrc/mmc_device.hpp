@@ -1,0 +1,288 @@
+// mmc_device.hpp -- device-side building blocks shared by every kernel of libmmc_hip.so.
+//
+// gfx950 (CDNA4) only: 64-lane wavefronts, 256-thread workgroups (one wave per SIMD), LDS for the
+// neighbour list, DPP/shuffle wave reductions.  No MFMA: nothing on this path is a dense
+// contraction (pairwise erfc/LJ terms and a 3-factor phase product).
+//
+// The arithmetic of each pair term follows the reference statement by statement (comparisons,
+// constants, order of operations inside a term); only the ORDER OF SUMMATION over pairs differs
+// (tree reduction instead of the reference's sequential loop), which is worth ~1e-13 relative.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MMC_BLOCK 256
+#define MMC_WAVES (MMC_BLOCK / 64)
+#define MMC_LIST_CAP 2048 // neighbour-list slots per chunk (8 KiB of LDS)
+#define MMC_MAX_ATOMS 16  // atoms in the CHOSEN molecule (neighbours are unbounded)
+#define MMC_NKTAB 11      // phase-table width for nk = 5: k = -5..5
+
+// One replica's state as the kernels see it.  Structure-of-arrays so that lane j reading
+// molecule j (or atom j) is a unit-stride, fully coalesced HBM/L2 access.
+struct SysView {
+    const double *comx, *comy, *comz; // [n_mol]   moa.COM
+    const double *ax, *ay, *az;       // [n_atoms] soa.coords
+    const int32_t *first0;            // [n_mol]   moa.firstAtom - 1
+    const int32_t *cnt;               // [n_mol]   lastAtom - firstAtom + 1
+    const int32_t *atype;             // [n_atoms] soa.atype - 1
+    const double *charge;             // [n_atoms] soa.charge
+    const double *eps, *sig;          // [n_types^2] column-major Tables
+    int32_t n_mol, n_atoms, n_types;
+    double box;
+};
+
+// The chosen molecule in up to two states (0 = old, 1 = new), staged in LDS.
+struct Chosen {
+    int32_t i0, na;
+    int32_t type[MMC_MAX_ATOMS];
+    double q[MMC_MAX_ATOMS];
+    double com[2][3];
+    double at[2][MMC_MAX_ATOMS][3];
+};
+
+// An accepted-but-not-yet-written move of this replica: every reader substitutes it for
+// molecule `mol` (so no inter-workgroup ordering is needed inside the launch that commits it).
+struct Pending {
+    int32_t mol; // 0-based, -1 = none
+    int32_t _pad;
+    double com[3];
+    double at[MMC_MAX_ATOMS][3];
+};
+
+struct PairParams {
+    double lj_gate_sq;  // (r_cut + diameter)^2, LJ          energy.jl:233-234
+    double qq_gate_sq;  // (r_cut + diameter)^2, Coulomb     ewalds.jl:313-314
+    double lj_slack_sq; // r_cut^2 + 100                     energy.jl:270
+    double qq_slack_sq; // r_cut^2 + 100 (Ewald) or r_cut^2 (bare, energy.jl:699)
+    double ovr;         // 0.5 (ewalds.jl:327), 1.0 (legacy :240, bare :652)
+    double kappa;
+};
+
+struct PairAcc {
+    double lj_pot, lj_vir, qq_pot;
+    int32_t ovl;
+};
+
+// Ewald/ewalds.jl:30-38 (== boundaries.jl:8-14): minimum image by comparison, not by rounding.
+__device__ __forceinline__ double vector1D(double c1, double c2, double box)
+{
+    double d = c2 - c1;
+    if (c1 < c2)
+        return d < (c1 - c2 + box) ? d : d - box;
+    else
+        return (c1 - c2) < (d + box) ? d : d + box;
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                     __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+        v += __shfl_down(v, off, 64);
+    return v; // lane 0 holds the sum
+}
+
+// Sum NV values over the 256-thread workgroup; thread 0 gets the totals in out[].
+// red: LDS scratch of NV * MMC_WAVES doubles.  Fixed order -> bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void block_sum(const double (&v)[NV], double *red, double (&out)[NV])
+{
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        double s = wave_sum(v[k]);
+        if (lane_id() == 0)
+            red[k * MMC_WAVES + wave_id()] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            double s = 0.0;
+#pragma unroll
+            for (int w = 0; w < MMC_WAVES; w++)
+                s += red[k * MMC_WAVES + w];
+            out[k] = s;
+        }
+    }
+    __syncthreads();
+}
+
+// STYLE 0: erfc-damped Coulomb (EwaldReal); STYLE 1: bare Coulomb (CoulombReal).
+//
+// Scan molecules [j_begin, j_end) of replica `s` against the chosen molecule in NS states.
+//   phase A  one lane per molecule j: COM minimum image against each state, gate test
+//            (energy.jl:248-254, ewalds.jl:334-340); survivors are compacted into an LDS list,
+//            each wave owning a contiguous j-range and a contiguous list segment so the list is
+//            in ascending j whatever the wave timing (deterministic summation order);
+//   phase B  one lane per (neighbour, atom a of the chosen molecule): loop over the neighbour's
+//            atoms b, both states share the loads of b (energy.jl:257-285, ewalds.jl:343-372).
+// acc[] accumulates per thread; the caller reduces.
+template <int NS, bool LJ, bool QQ, int STYLE, bool PEND>
+__device__ __forceinline__ void pair_scan(const SysView &s, const Chosen *ch, const Pending *pd,
+                                          int j_begin, int j_end, const PairParams &pp,
+                                          int32_t *list, int32_t *wcnt, PairAcc (&acc)[NS])
+{
+    const double box = s.box;
+    const int i0 = ch->i0, na = ch->na;
+    const int pend = PEND ? pd->mol : -1;
+    const double gate = fmax(LJ ? pp.lj_gate_sq : 0.0, QQ ? pp.qq_gate_sq : 0.0);
+
+    for (int jb = j_begin; jb < j_end; jb += MMC_LIST_CAP) {
+        const int je = min(jb + MMC_LIST_CAP, j_end);
+        const int len = je - jb;
+        const int seg = ((len + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64; // per-wave slots
+        const int w = wave_id();
+        const int wj0 = jb + w * seg, wj1 = min(wj0 + seg, je);
+
+        // ---- phase A ----
+        int count = 0; // wave-uniform
+        for (int base = wj0; base < wj1; base += 64) {
+            const int j = base + lane_id();
+            bool keep = false;
+            if (j < wj1 && j != i0) {
+                double cx, cy, cz;
+                if (PEND && j == pend) {
+                    cx = pd->com[0]; cy = pd->com[1]; cz = pd->com[2];
+                } else {
+                    cx = s.comx[j]; cy = s.comy[j]; cz = s.comz[j];
+                }
+#pragma unroll
+                for (int st = 0; st < NS; st++) {
+                    double dx = vector1D(ch->com[st][0], cx, box);
+                    double dy = vector1D(ch->com[st][1], cy, box);
+                    double dz = vector1D(ch->com[st][2], cz, box);
+                    double r2 = dx * dx + dy * dy + dz * dz;
+                    keep = keep || (r2 < gate);
+                }
+            }
+            unsigned long long m = __ballot(keep);
+            if (keep)
+                list[w * seg + count + lanes_below(m)] = j;
+            count += __popcll(m);
+        }
+        if (lane_id() == 0)
+            wcnt[w] = count;
+        __syncthreads();
+
+        // ---- phase B ----
+        int c0 = wcnt[0], c1 = wcnt[1], c2 = wcnt[2], c3 = wcnt[3];
+        const int total = c0 + c1 + c2 + c3;
+        for (int g = threadIdx.x; g < total * na; g += MMC_BLOCK) {
+            const int n = g / na, a = g - n * na;
+            int slot;
+            if (n < c0) slot = n;
+            else if (n < c0 + c1) slot = seg + (n - c0);
+            else if (n < c0 + c1 + c2) slot = 2 * seg + (n - c0 - c1);
+            else slot = 3 * seg + (n - c0 - c1 - c2);
+            const int j = list[slot];
+            const bool jp = PEND && (j == pend);
+
+            double cx, cy, cz;
+            if (jp) { cx = pd->com[0]; cy = pd->com[1]; cz = pd->com[2]; }
+            else { cx = s.comx[j]; cy = s.comy[j]; cz = s.comz[j]; }
+            double rij[NS][3];
+            bool lj_on[NS], qq_on[NS];
+#pragma unroll
+            for (int st = 0; st < NS; st++) {
+                rij[st][0] = vector1D(ch->com[st][0], cx, box);
+                rij[st][1] = vector1D(ch->com[st][1], cy, box);
+                rij[st][2] = vector1D(ch->com[st][2], cz, box);
+                double r2 = rij[st][0] * rij[st][0] + rij[st][1] * rij[st][1] +
+                            rij[st][2] * rij[st][2];
+                lj_on[st] = LJ && (r2 < pp.lj_gate_sq);
+                qq_on[st] = QQ && (r2 < pp.qq_gate_sq);
+            }
+            const int fb = s.first0[j], nb = s.cnt[j];
+            const int ta = ch->type[a];
+            const double qa = ch->q[a];
+            for (int b = 0; b < nb; b++) {
+                double bx, by, bz;
+                if (jp) { bx = pd->at[b][0]; by = pd->at[b][1]; bz = pd->at[b][2]; }
+                else { bx = s.ax[fb + b]; by = s.ay[fb + b]; bz = s.az[fb + b]; }
+                const int tb = s.atype[fb + b];
+                const double qb = QQ ? s.charge[fb + b] : 0.0;
+                double e = 0.0, sg = 0.0;
+                if (LJ) {
+                    e = s.eps[ta + tb * s.n_types];
+                    sg = s.sig[ta + tb * s.n_types];
+                }
+#pragma unroll
+                for (int st = 0; st < NS; st++) {
+                    double rx = vector1D(ch->at[st][a][0], bx, box);
+                    double ry = vector1D(ch->at[st][a][1], by, box);
+                    double rz = vector1D(ch->at[st][a][2], bz, box);
+                    double rab2 = rx * rx + ry * ry + rz * rz;
+                    if (QQ && qq_on[st]) {
+                        if ((rab2 < pp.ovr) && (qa * qb < 0)) {
+                            acc[st].ovl = 1;
+                        } else if (rab2 < pp.qq_slack_sq) {
+                            if (STYLE == 0) {
+                                double rab_mag = sqrt(rab2);
+                                acc[st].qq_pot += qa * qb * erfc(pp.kappa * rab_mag) / rab_mag;
+                            } else {
+                                acc[st].qq_pot += qa * qb / sqrt(rab2);
+                            }
+                        }
+                    }
+                    if (LJ && lj_on[st]) {
+                        if (rab2 < pp.lj_slack_sq && e > 0.001) {
+                            double s2 = sg * sg / rab2;
+                            double s6 = s2 * s2 * s2;
+                            double s12 = s6 * s6;
+                            acc[st].lj_pot += e * (s12 - s6);
+                            double virab = e * (2.0 * s12 - s6);
+                            double f0 = rx * virab * s2, f1 = ry * virab * s2,
+                                   f2 = rz * virab * s2;
+                            acc[st].lj_vir += rij[st][0] * f0 + rij[st][1] * f1 +
+                                              rij[st][2] * f2;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads(); // list is reused by the next chunk
+    }
+}
+
+// ---- complex helpers (plain, unfused: the reference's Complex{Float64} arithmetic) -------------
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx c_mul(cplx a, cplx b)
+{
+    cplx r;
+    r.re = a.re * b.re - a.im * b.im;
+    r.im = a.re * b.im + a.im * b.re;
+    return r;
+}
+__device__ __forceinline__ cplx c_conj(cplx a) { cplx r = { a.re, -a.im }; return r; }
+__device__ __forceinline__ cplx c_rmul(double q, cplx a) { cplx r = { q * a.re, q * a.im }; return r; }
+
+#define MMC_TWOPI (2.0 * 3.141592653589793)
+
+// One row of the e^{i 2 pi k x / L} table, k = -5..5, by the recurrence of ewalds.jl:564-585
+// (same in RecipMove :762-796): cos/sin for k = 1, products above, conjugates below.
+__device__ __forceinline__ void phase_row(double x, double L, cplx *row /* [MMC_NKTAB] */)
+{
+    double ang = MMC_TWOPI * x / L;
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    cplx e1 = { cs, sn };
+    cplx one = { 1.0, 0.0 };
+    row[5] = one;
+    row[6] = e1;
+    row[4] = c_conj(e1);
+    cplx p = e1;
+#pragma unroll
+    for (int k = 2; k <= 5; k++) {
+        p = c_mul(p, e1);
+        row[5 + k] = p;
+        row[5 - k] = c_conj(p);
+    }
+}

@@ -1,0 +1,81 @@
+// mmc_host.hpp -- host-side state shared by the context, batch and engine translation units.
+#pragma once
+#include "../../include/mmc_hip.h"
+#include "mmc_kernels.hpp"
+#include <string>
+#include <vector>
+
+void mmc_set_error(const char *fmt, ...);
+
+#define MMC_HIP(call)                                                                            \
+    do {                                                                                         \
+        hipError_t e__ = (call);                                                                 \
+        if (e__ != hipSuccess) {                                                                 \
+            mmc_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,      \
+                          __LINE__);                                                             \
+            return MMC_ERR_HIP;                                                                  \
+        }                                                                                        \
+    } while (0)
+
+#define MMC_REQUIRE(cond, code, ...)                                                             \
+    do {                                                                                         \
+        if (!(cond)) {                                                                           \
+            mmc_set_error(__VA_ARGS__);                                                          \
+            return (code);                                                                       \
+        }                                                                                        \
+    } while (0)
+
+#define MMC_TRY(expr)                                                                            \
+    do {                                                                                         \
+        int32_t st__ = (expr);                                                                   \
+        if (st__ != MMC_OK)                                                                      \
+            return st__;                                                                         \
+    } while (0)
+
+#define MMC_NK_STRIDE 352 // >= 337 k-vectors, 16-element aligned
+
+// Device state of R replicas of one system + Ewald tables.  R = 1 for a context.
+struct DeviceSystem {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int64_t R = 0, n_mol = 0, n_atoms = 0, n_types = 0;
+    double box = 0.0;
+    bool uploaded = false, ewald_ready = false, uniform3 = false;
+    int64_t nk = 0, k_sq_max = 0, nkvecs = 0;
+    BatchView bv{};
+    std::vector<void *> allocs; // hipMalloc'ed
+    std::vector<int32_t> h_first0, h_cnt;
+    std::vector<double> h_charge;
+    // scratch
+    MolE *d_permol = nullptr;      // [R][n_mol]
+    void *h_res = nullptr;         // pinned, mapped: small per-call results (4 KiB)
+    void *d_res = nullptr;         // device alias of h_res
+    double *d_stage = nullptr;     // device staging for AoS uploads/downloads (3*n_atoms)
+    std::vector<double> h_stage;
+
+    int32_t init(int dev, void *hip_stream, int64_t replicas);
+    void release();
+    int32_t dmalloc(void **p, size_t bytes);
+    int32_t upload(int64_t n_mol_, int64_t n_atoms_, const double *com,
+                   const int64_t *first_atom, const int64_t *last_atom, const double *coords,
+                   const int64_t *atype, const double *charge, int64_t n_types_,
+                   const double *eps, const double *sig, double box_);
+    int32_t set_replica(int64_t r, const double *com, const double *coords);
+    int32_t get_replica(int64_t r, double *com, double *coords);
+    int32_t broadcast_replica0();
+    int32_t prepare_ewald(double kappa, int64_t nk_, int64_t k_sq_max_, double box_,
+                          double factor, int64_t *nkvecs_out);
+    int32_t sync();
+    // per-molecule energies for molecules [i_base, i_base + n_sel) of every replica
+    int32_t mol_energy(int i_base, int n_sel, bool lj, bool qq, int style, const PairParams &pp,
+                       MolE *out, int out_stride);
+    int32_t recip_long_all(double *energies_host /* [R] */);
+    int32_t totals_ewald(double lj_rcut, double qq_rcut, mmc_totals *tot /* [R] */);
+    int32_t charge_sums(double *sum_q, double *sum_q2);
+};
+
+PairParams mmc_pair_params(double lj_rcut, double qq_rcut, double diameter, double ovr,
+                           double kappa, bool bare);
+
+void mmc_combine_parts(const PartOut *parts, int n_parts, double factor, mmc_move_result *res);

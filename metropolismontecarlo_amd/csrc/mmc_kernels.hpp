@@ -1,0 +1,457 @@
+// mmc_kernels.hpp -- the HIP kernels of libmmc_hip.so (gfx950).
+//
+//   k_mol_energy     K1/K2  one chosen molecule vs all others: LJ_poly_dU + EwaldReal/CoulombReal
+//   k_totals         K2     per-replica sums of k_mol_energy's per-molecule results
+//   k_recip_long     K3     S(k) = sum_l q_l e^{ik.r_l}: one workgroup per (kx, ky) column
+//   k_recip_energy   K3     sum_k cfac_k |S(k)|^2
+//   k_recip_move     K4     dS(k) for the moved atoms of ONE system (context API)
+//   k_move_eval      K1+K4  one trial move per replica, fused: 2x LJ_poly_dU + 2x EwaldShort +
+//                           RecipMove, plus the commit of the replica's previous accepted move
+//   k_set_molecule / k_settle / k_charge_sums / k_copy_s   small state updates
+#pragma once
+#include "mmc_device.hpp"
+
+// Device state of R replicas (R = 1 for a context).  Coordinates are SoA per replica.
+struct BatchView {
+    double *comx, *comy, *comz; // [R][mol_stride]
+    double *ax, *ay, *az;       // [R][atom_stride]
+    int64_t mol_stride, atom_stride;
+    const int32_t *first0, *cnt, *atype; // shared topology
+    const double *charge, *eps, *sig;
+    int32_t n_mol, n_atoms, n_types;
+    double box;
+    // Ewald
+    double *S;           // [R][2][nk_stride] complex (re, im): two structure-factor buffers
+    int64_t nk_stride;   // in complex elements
+    const int32_t *kxyz; // [nkvecs][3]
+    const double *cfac;  // [nkvecs]
+    const int16_t *kmap; // [(nk+1)*(2nk+1)*(2nk+1)] -> k index or -1
+    int32_t nkvecs, nk;
+    double kappa, factor;
+};
+
+__device__ __forceinline__ SysView sys_view(const BatchView &b, int r)
+{
+    SysView s;
+    s.comx = b.comx + r * b.mol_stride;
+    s.comy = b.comy + r * b.mol_stride;
+    s.comz = b.comz + r * b.mol_stride;
+    s.ax = b.ax + r * b.atom_stride;
+    s.ay = b.ay + r * b.atom_stride;
+    s.az = b.az + r * b.atom_stride;
+    s.first0 = b.first0; s.cnt = b.cnt; s.atype = b.atype;
+    s.charge = b.charge; s.eps = b.eps; s.sig = b.sig;
+    s.n_mol = b.n_mol; s.n_atoms = b.n_atoms; s.n_types = b.n_types;
+    s.box = b.box;
+    return s;
+}
+
+__device__ __forceinline__ double *s_buf(const BatchView &b, int r, int which)
+{
+    return b.S + ((int64_t)r * 2 + which) * b.nk_stride * 2;
+}
+
+struct MolE {
+    double lj_pot, lj_vir, qq_pot;
+    int32_t ovl, _pad;
+};
+
+// ---- K1/K2: chosen molecule i = i_base + blockIdx.x of replica blockIdx.y vs everyone ---------
+template <bool LJ, bool QQ, int STYLE>
+__global__ __launch_bounds__(MMC_BLOCK) void k_mol_energy(BatchView bv, int i_base, PairParams pp,
+                                                          MolE *out, int out_stride)
+{
+    __shared__ Chosen ch;
+    __shared__ int32_t list[MMC_LIST_CAP];
+    __shared__ int32_t wcnt[MMC_WAVES];
+    __shared__ double red[3 * MMC_WAVES];
+    const int r = blockIdx.y, i0 = i_base + blockIdx.x;
+    const SysView s = sys_view(bv, r);
+    const int na = min(s.cnt[i0], MMC_MAX_ATOMS);
+    if (threadIdx.x < na) {
+        const int a = s.first0[i0] + threadIdx.x;
+        ch.at[0][threadIdx.x][0] = s.ax[a];
+        ch.at[0][threadIdx.x][1] = s.ay[a];
+        ch.at[0][threadIdx.x][2] = s.az[a];
+        ch.q[threadIdx.x] = s.charge[a];
+        ch.type[threadIdx.x] = s.atype[a];
+    }
+    if (threadIdx.x == 0) {
+        ch.i0 = i0; ch.na = na;
+        ch.com[0][0] = s.comx[i0]; ch.com[0][1] = s.comy[i0]; ch.com[0][2] = s.comz[i0];
+    }
+    __syncthreads();
+    PairAcc acc[1] = { { 0.0, 0.0, 0.0, 0 } };
+    pair_scan<1, LJ, QQ, STYLE, false>(s, &ch, nullptr, 0, s.n_mol, pp, list, wcnt, acc);
+    double v[3] = { acc[0].lj_pot, acc[0].lj_vir, acc[0].qq_pot }, tot[3];
+    const int ovl = __syncthreads_or(acc[0].ovl);
+    block_sum<3>(v, red, tot);
+    if (threadIdx.x == 0) {
+        MolE m;
+        m.lj_pot = tot[0]; m.lj_vir = tot[1];
+        m.qq_pot = ovl ? 0.0 : tot[2]; // ewalds.jl:359-360: `return 0.0, true`
+        m.ovl = ovl; m._pad = 0;
+        out[(int64_t)r * out_stride + blockIdx.x] = m;
+    }
+}
+
+struct TotalsRaw {
+    double lj_e, lj_v, qq; // sum_i 4*pot_i ; sum_i 24*vir_i/3 ; sum_i EwaldReal_i
+    int32_t n_ovl, _pad;
+};
+
+// energy.jl:972-977 and :991-1000: the per-molecule loop sums (halving is done by the host).
+__global__ __launch_bounds__(MMC_BLOCK) void k_totals(const MolE *per_mol, int n_mol, int stride,
+                                                      TotalsRaw *out)
+{
+    __shared__ double red[4 * MMC_WAVES];
+    const int r = blockIdx.x;
+    double v[4] = { 0, 0, 0, 0 }, tot[4];
+    for (int i = threadIdx.x; i < n_mol; i += MMC_BLOCK) {
+        const MolE m = per_mol[(int64_t)r * stride + i];
+        v[0] += m.lj_pot * 4;        // energy.jl:289
+        v[1] += m.lj_vir * 24 / 3.0;
+        v[2] += m.qq_pot;
+        v[3] += (double)m.ovl;
+    }
+    block_sum<4>(v, red, tot);
+    if (threadIdx.x == 0) {
+        TotalsRaw t;
+        t.lj_e = tot[0]; t.lj_v = tot[1]; t.qq = tot[2];
+        t.n_ovl = (int)tot[3]; t._pad = 0;
+        out[r] = t;
+    }
+}
+
+// ---- K3: full structure factor -----------------------------------------------------------------
+// grid (nk+1)*(2nk+1) x R.  The workgroup owns one (kx, ky) and accumulates all 2nk+1 kz at once:
+// per atom 3 sincos, the reference's power recurrence, and 11 complex multiply-adds that share
+// q*e^{ikx x}*e^{iky y} (ewalds.jl:589-597).  Atoms are read unit-stride.  nk == 5 only.
+__global__ __launch_bounds__(MMC_BLOCK) void k_recip_long(BatchView bv)
+{
+    __shared__ double red[2 * MMC_NKTAB * MMC_WAVES];
+    const int r = blockIdx.y;
+    const int kx = blockIdx.x / MMC_NKTAB, ky = blockIdx.x % MMC_NKTAB - 5;
+    const SysView s = sys_view(bv, r);
+    const double L = s.box;
+    double acc[2 * MMC_NKTAB];
+#pragma unroll
+    for (int k = 0; k < 2 * MMC_NKTAB; k++)
+        acc[k] = 0.0;
+    const int aky = ky < 0 ? -ky : ky;
+    for (int l = threadIdx.x; l < s.n_atoms; l += MMC_BLOCK) {
+        const double q = s.charge[l];
+        double sn, cs;
+        sincos(MMC_TWOPI * s.ax[l] / L, &sn, &cs);
+        const cplx x1 = { cs, sn };
+        sincos(MMC_TWOPI * s.ay[l] / L, &sn, &cs);
+        const cplx y1 = { cs, sn };
+        cplx ex = { 1.0, 0.0 }, ey = { 1.0, 0.0 };
+        if (kx > 0) {
+            ex = x1;
+            for (int k = 2; k <= kx; k++)
+                ex = c_mul(ex, x1);
+        }
+        if (aky > 0) {
+            ey = y1;
+            for (int k = 2; k <= aky; k++)
+                ey = c_mul(ey, y1);
+            if (ky < 0)
+                ey = c_conj(ey);
+        }
+        cplx ez[MMC_NKTAB];
+        phase_row(s.az[l], L, ez);
+        const cplx qxy = c_mul(c_rmul(q, ex), ey); // (q*eikx)*eiky
+#pragma unroll
+        for (int k = 0; k < MMC_NKTAB; k++) {
+            const cplx t = c_mul(qxy, ez[k]);
+            acc[2 * k] += t.re;
+            acc[2 * k + 1] += t.im;
+        }
+    }
+    double tot[2 * MMC_NKTAB];
+    block_sum<2 * MMC_NKTAB>(acc, red, tot);
+    if (threadIdx.x == 0) {
+        double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
+#pragma unroll
+        for (int k = 0; k < MMC_NKTAB; k++) {
+            const int idx = bv.kmap[(kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB + k];
+            if (idx >= 0) { // ewalds.jl:600-601: both arrays get `term`
+                s0[2 * idx] = tot[2 * k]; s0[2 * idx + 1] = tot[2 * k + 1];
+                s1[2 * idx] = tot[2 * k]; s1[2 * idx + 1] = tot[2 * k + 1];
+            }
+        }
+    }
+}
+
+// ewalds.jl:599: energy += cfac[i] * real(conj(term) * term), no factor.
+__global__ __launch_bounds__(MMC_BLOCK) void k_recip_energy(BatchView bv, int which, double *out)
+{
+    __shared__ double red[MMC_WAVES];
+    const int r = blockIdx.x;
+    const double *S = s_buf(bv, r, which);
+    double v[1] = { 0.0 }, tot[1];
+    for (int k = threadIdx.x; k < bv.nkvecs; k += MMC_BLOCK) {
+        const double re = S[2 * k], im = S[2 * k + 1];
+        v[0] += bv.cfac[k] * (re * re - (-im) * im);
+    }
+    block_sum<1>(v, red, tot);
+    if (threadIdx.x == 0)
+        out[r] = tot[0];
+}
+
+// ---- K4 (context API): RecipMove for one system, explicit old/new arrays -----------------------
+struct RecipMoveArgs {
+    double r_old[9], r_new[9], q[3];
+};
+
+// ewalds.jl:718-826.  S(0) = sumQExpOld, S(1) = sumQExpNew; S(1) += dS in place (:805-814).
+__global__ __launch_bounds__(MMC_BLOCK) void k_recip_move(BatchView bv, RecipMoveArgs a,
+                                                          double *out)
+{
+    __shared__ cplx tab[2][3][3][MMC_NKTAB];
+    __shared__ double red[MMC_WAVES];
+    if (threadIdx.x < 18) {
+        const int st = threadIdx.x / 9, l = (threadIdx.x % 9) / 3, d = threadIdx.x % 3;
+        const double x = st ? a.r_new[3 * l + d] : a.r_old[3 * l + d];
+        phase_row(x, bv.box, tab[st][l][d]);
+    }
+    __syncthreads();
+    const double *So = s_buf(bv, 0, 0);
+    double *Sn = s_buf(bv, 0, 1);
+    double v[1] = { 0.0 }, tot[1];
+    for (int k = threadIdx.x; k < bv.nkvecs; k += MMC_BLOCK) {
+        const int kx = bv.kxyz[3 * k], ky = bv.kxyz[3 * k + 1], kz = bv.kxyz[3 * k + 2];
+        double nr = Sn[2 * k], ni = Sn[2 * k + 1];
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            const cplx tn = c_mul(c_mul(tab[1][l][0][5 + kx], tab[1][l][1][5 + ky]),
+                                  tab[1][l][2][5 + kz]);
+            const cplx to = c_mul(c_mul(tab[0][l][0][5 + kx], tab[0][l][1][5 + ky]),
+                                  tab[0][l][2][5 + kz]);
+            nr += a.q[l] * (tn.re - to.re);
+            ni += a.q[l] * (tn.im - to.im);
+        }
+        Sn[2 * k] = nr; Sn[2 * k + 1] = ni;
+        const double orr = So[2 * k], oi = So[2 * k + 1];
+        v[0] += bv.cfac[k] * ((nr * nr - (-ni) * ni) - (orr * orr - (-oi) * oi));
+    }
+    block_sum<1>(v, red, tot);
+    if (threadIdx.x == 0)
+        out[0] = tot[0];
+}
+
+// ---- K1+K4 fused, batched: one trial move per replica ------------------------------------------
+// Layout-compatible with mmc_move (include/mmc_hip.h); `flags` reuses accept_prev:
+// bit 0 = commit this replica's previous proposal, bit 1 = which S buffer is current.
+struct MoveRec {
+    int32_t mol, flags;
+    double com_new[3];
+    double atoms_new[9];
+};
+
+struct PartOut {
+    double lj_pot[2], lj_vir[2], qq_pot[2]; // [old, new] raw sums of this workgroup's j-range
+    double recip;                           // sum_k cfac (|S_new|^2 - |S_old|^2), no factor
+    int32_t ovl[2];
+};
+
+// grid (n_parts, R).  n_parts == 1: the workgroup scans all molecules and then does the
+// reciprocal part.  n_parts > 1: parts 0..n_parts-2 split the molecule range, the last part does
+// the reciprocal part -- this is how a small replica count still fills 256 CUs.
+__global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const MoveRec *cur,
+                                                         const MoveRec *prev, PartOut *out,
+                                                         int n_parts, PairParams pp, int r_base)
+{
+    __shared__ Chosen ch;
+    __shared__ Pending pd;
+    __shared__ int32_t list[MMC_LIST_CAP];
+    __shared__ int32_t wcnt[MMC_WAVES];
+    __shared__ double red[6 * MMC_WAVES];
+    __shared__ cplx tab[2][3][3][MMC_NKTAB];
+
+    const int r = r_base + blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const SysView s = sys_view(bv, r);
+    const MoveRec *mv = cur + r;
+    const int flags = mv->flags;
+    const bool commit = prev && (flags & 1);
+    const int scur = (flags >> 1) & 1;
+    const int i0 = mv->mol - 1;
+    const int pend = commit ? prev[r].mol - 1 : -1;
+
+    if (tid == 0) {
+        pd.mol = pend;
+        ch.i0 = i0; ch.na = 3;
+    }
+    if (commit && tid < 12) {
+        if (tid < 3) pd.com[tid] = prev[r].com_new[tid];
+        else pd.at[(tid - 3) / 3][(tid - 3) % 3] = prev[r].atoms_new[tid - 3];
+    }
+    __syncthreads();
+    // the chosen molecule: state 0 = old (device state, or the pending commit), 1 = proposal
+    if (tid < 3) {
+        const int a = s.first0[i0] + tid;
+        if (i0 == pend) {
+            ch.at[0][tid][0] = pd.at[tid][0]; ch.at[0][tid][1] = pd.at[tid][1];
+            ch.at[0][tid][2] = pd.at[tid][2];
+            ch.com[0][tid] = pd.com[tid];
+        } else {
+            ch.at[0][tid][0] = s.ax[a]; ch.at[0][tid][1] = s.ay[a]; ch.at[0][tid][2] = s.az[a];
+            ch.com[0][tid] = (tid == 0 ? s.comx[i0] : tid == 1 ? s.comy[i0] : s.comz[i0]);
+        }
+        ch.at[1][tid][0] = mv->atoms_new[3 * tid];
+        ch.at[1][tid][1] = mv->atoms_new[3 * tid + 1];
+        ch.at[1][tid][2] = mv->atoms_new[3 * tid + 2];
+        ch.com[1][tid] = mv->com_new[tid];
+        ch.q[tid] = s.charge[a];
+        ch.type[tid] = s.atype[a];
+    }
+    // commit of the previous accepted move (main.jl:598-621): one workgroup writes it; every
+    // reader in this launch substitutes `pd` for that molecule, so no ordering is required.
+    if (part == 0 && commit && tid < 12) {
+        double *w;
+        const int fa = s.first0[pend];
+        if (tid < 3) {
+            w = (tid == 0 ? bv.comx : tid == 1 ? bv.comy : bv.comz) + r * bv.mol_stride + pend;
+            *w = prev[r].com_new[tid];
+        } else {
+            const int a = (tid - 3) / 3, d = (tid - 3) % 3;
+            w = (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az) + r * bv.atom_stride + fa + a;
+            *w = prev[r].atoms_new[tid - 3];
+        }
+    }
+    __syncthreads();
+
+    const bool do_pairs = (n_parts == 1) || (part < n_parts - 1);
+    const bool do_recip = (n_parts == 1) || (part == n_parts - 1);
+    PartOut po;
+    po.lj_pot[0] = po.lj_pot[1] = po.lj_vir[0] = po.lj_vir[1] = 0.0;
+    po.qq_pot[0] = po.qq_pot[1] = po.recip = 0.0;
+    po.ovl[0] = po.ovl[1] = 0;
+
+    if (do_pairs) {
+        const int np = (n_parts == 1) ? 1 : n_parts - 1;
+        const int len = (s.n_mol + np - 1) / np;
+        const int j0 = part * len, j1 = min(j0 + len, s.n_mol);
+        PairAcc acc[2] = { { 0.0, 0.0, 0.0, 0 }, { 0.0, 0.0, 0.0, 0 } };
+        pair_scan<2, true, true, 0, true>(s, &ch, &pd, j0, j1, pp, list, wcnt, acc);
+        double v[6] = { acc[0].lj_pot, acc[1].lj_pot, acc[0].lj_vir,
+                        acc[1].lj_vir, acc[0].qq_pot, acc[1].qq_pot }, tot[6];
+        const int o0 = __syncthreads_or(acc[0].ovl), o1 = __syncthreads_or(acc[1].ovl);
+        block_sum<6>(v, red, tot);
+        if (tid == 0) {
+            po.lj_pot[0] = tot[0]; po.lj_pot[1] = tot[1];
+            po.lj_vir[0] = tot[2]; po.lj_vir[1] = tot[3];
+            po.qq_pot[0] = tot[4]; po.qq_pot[1] = tot[5];
+            po.ovl[0] = o0; po.ovl[1] = o1;
+        }
+    }
+    if (do_recip) {
+        if (tid < 18) {
+            const int st = tid / 9, l = (tid % 9) / 3, d = tid % 3;
+            phase_row(ch.at[st][l][d], s.box, tab[st][l][d]);
+        }
+        __syncthreads();
+        const double *So = s_buf(bv, r, scur);
+        double *Sn = s_buf(bv, r, scur ^ 1);
+        double v[1] = { 0.0 }, tot[1];
+        for (int k = tid; k < bv.nkvecs; k += MMC_BLOCK) {
+            const int kx = bv.kxyz[3 * k], ky = bv.kxyz[3 * k + 1], kz = bv.kxyz[3 * k + 2];
+            const double orr = So[2 * k], oi = So[2 * k + 1];
+            double nr = orr, ni = oi;
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                const cplx tn = c_mul(c_mul(tab[1][l][0][5 + kx], tab[1][l][1][5 + ky]),
+                                      tab[1][l][2][5 + kz]);
+                const cplx to = c_mul(c_mul(tab[0][l][0][5 + kx], tab[0][l][1][5 + ky]),
+                                      tab[0][l][2][5 + kz]);
+                nr += ch.q[l] * (tn.re - to.re);
+                ni += ch.q[l] * (tn.im - to.im);
+            }
+            Sn[2 * k] = nr; Sn[2 * k + 1] = ni;
+            v[0] += bv.cfac[k] * ((nr * nr - (-ni) * ni) - (orr * orr - (-oi) * oi));
+        }
+        block_sum<1>(v, red, tot);
+        if (tid == 0)
+            po.recip = tot[0];
+    }
+    if (tid == 0)
+        out[(int64_t)r * n_parts + part] = po;
+}
+
+// ---- small state updates -----------------------------------------------------------------------
+struct SetMolArgs {
+    int32_t r, i0, na, _pad;
+    double com[3];
+    double at[MMC_MAX_ATOMS][3];
+};
+
+__global__ void k_set_molecule(BatchView bv, SetMolArgs a)
+{
+    const int t = threadIdx.x;
+    if (t < 3)
+        (t == 0 ? bv.comx : t == 1 ? bv.comy : bv.comz)[a.r * bv.mol_stride + a.i0] = a.com[t];
+    if (t < a.na) {
+        const int64_t o = a.r * bv.atom_stride + bv.first0[a.i0] + t;
+        bv.ax[o] = a.at[t][0]; bv.ay[o] = a.at[t][1]; bv.az[o] = a.at[t][2];
+    }
+}
+
+// Commit the outstanding proposal of every replica whose accept flag is set (main.jl:598-621),
+// without evaluating a new one.  grid R, block 64.
+__global__ void k_settle(BatchView bv, const MoveRec *prev, const int32_t *accept, int r_base)
+{
+    const int r = r_base + blockIdx.x, t = threadIdx.x;
+    if (!accept[r] || t >= 12)
+        return;
+    const int m = prev[r].mol - 1;
+    if (t < 3) {
+        (t == 0 ? bv.comx : t == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + m] =
+            prev[r].com_new[t];
+    } else {
+        const int a = (t - 3) / 3, d = (t - 3) % 3;
+        (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + bv.first0[m] + a] =
+            prev[r].atoms_new[t - 3];
+    }
+}
+
+// sum q and sum q^2 (EwaldSelf ewalds.jl:832; Wolf terms energy.jl:924-932)
+__global__ __launch_bounds__(MMC_BLOCK) void k_charge_sums(const double *q, int n, double *out)
+{
+    __shared__ double red[2 * MMC_WAVES];
+    double v[2] = { 0.0, 0.0 }, tot[2];
+    for (int i = threadIdx.x; i < n; i += MMC_BLOCK) {
+        v[0] += q[i];
+        v[1] += q[i] * q[i];
+    }
+    block_sum<2>(v, red, tot);
+    if (threadIdx.x == 0) {
+        out[0] = tot[0];
+        out[1] = tot[1];
+    }
+}
+
+// S(dst) = S(src) for replica 0: main.jl:621 (commit: old <- new) / :628 (rollback: new <- old)
+__global__ void k_copy_s(BatchView bv, int dst, int src)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 2 * bv.nkvecs)
+        s_buf(bv, 0, dst)[k] = s_buf(bv, 0, src)[k];
+}
+
+// AoS (Julia Vector{SVector{3,Float64}}) -> SoA for one replica; n elements.
+__global__ void k_aos_to_soa(const double *aos, double *x, double *y, double *z, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        x[i] = aos[3 * i]; y[i] = aos[3 * i + 1]; z[i] = aos[3 * i + 2];
+    }
+}
+__global__ void k_soa_to_aos(const double *x, const double *y, const double *z, double *aos,
+                             int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
+    }
+}

@@ -1,0 +1,222 @@
+"""GPU parity for the replica batch (mmc_batch_*): one fused launch per step for R replicas, the
+commit-by-substitution of accepted moves, the S(k) buffer flip, and the native host driver.
+
+Tolerance: TOL = 1e-9 relative to the per-molecule energy scale (north_star asks 1e-6).
+"""
+import numpy as np
+import pytest
+
+import common
+from common import rel
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-9
+RCUT = 10.0
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def make_batch(a, R, **kw):
+    from metropolismontecarlo_amd import structs
+    from metropolismontecarlo_amd.device import Batch
+    return Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+                 5.6 / a["box"], structs.factor, RCUT, RCUT, **kw)
+
+
+def oracle_chain(orc, a, moves, accept_rule):
+    """Run `moves` through the oracle with accept_rule(step, overlap) -> bool.  Returns the list
+    of (d, overlap, accept) and the final (system, ewald)."""
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    out = []
+    for n, mv in enumerate(moves):
+        i = mv["mol"]
+        cn, an = np.array(mv["com_new"]), np.array(mv["atoms_new"])
+        d, ov = orc.trial_move(i, s, ew, RCUT, RCUT, cn, an)
+        acc = bool(accept_rule(n, ov)) and not ov
+        if acc:
+            s.com[i - 1] = cn
+            s.coords[3 * (i - 1):3 * i] = an
+            ew.sumQExpOld = ew.sumQExpNew.copy()
+        else:
+            ew.sumQExpNew = ew.sumQExpOld.copy()
+        out.append((d, ov, acc))
+    return out, s, ew
+
+
+@pytest.mark.parametrize("k,variant,parts", [(1, "reference", 1), (1, "reference", 4),
+                                             (4, "reference", 0), (4, "unwrapped", 9),
+                                             (2, "unwrapped", 2)])
+def test_batch_eval_chain(k, variant, parts, orc):
+    """Three replicas take the same proposals but different accept decisions, so their states
+    diverge; every step's dU terms, overlap flags and the final device state (coordinates and
+    S(k)) must match three independent oracle chains.  Proposals that touch the same molecule
+    twice in a row and the 'previous move accepted' substitution are both exercised."""
+    a = common.nist_arrays(k, variant)
+    g = common.golden(k, variant)
+    moves = list(g["moves"])
+    # re-propose the molecule of an accepted move immediately (pending-commit == chosen molecule)
+    extra = dict(moves[0])
+    extra["com_new"] = (np.array(extra["com_new"]) + 0.05).tolist()
+    extra["atoms_new"] = (np.array(extra["atoms_new"]) + 0.05).tolist()
+    moves.insert(1, extra)
+    rules = [lambda n, ov: True, lambda n, ov: False, lambda n, ov: n % 2 == 0]
+    chains = [oracle_chain(orc, a, moves, r) for r in rules]
+    R = len(rules)
+    with make_batch(a, R) as b:
+        if parts:
+            b.set_parts(parts)
+        e0 = b.recip_long()
+        ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
+        assert rel(e0[0], orc.recip_long(ew, a["coords"], a["charge"], a["box"])) < TOL
+        assert np.array_equal(e0, np.full(R, e0[0]))
+        acc_prev = np.zeros(R, dtype=bool)
+        for n, mv in enumerate(moves):
+            d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (R, 1)),
+                           np.tile(np.array(mv["atoms_new"]).ravel(), (R, 1)), acc_prev)
+            for r in range(R):
+                do, ovo, acco = chains[r][0][n]
+                assert ov[r] == ovo, (n, r)
+                scale = np.abs(do).max() + 1e4
+                assert np.abs(d[r] - do).max() < TOL * scale, (n, r, d[r], do)
+                acc_prev[r] = acco
+        b.settle(acc_prev)
+        for r in range(R):
+            com, coords, S = b.get_replica(r)
+            _, s, ewr = chains[r]
+            assert np.array_equal(com, s.com) and np.array_equal(coords, s.coords), r
+            assert np.abs(S - ewr.sumQExpOld).max() < 1e-11 * np.abs(ewr.sumQExpOld).max(), r
+        tot = b.potential_ewald()
+        for r in range(R):
+            _, s, _ = chains[r]
+            to = orc.potential_ewald(s, orc.Ewald(5.6 / s.box, 5, 27, s.box), RCUT, RCUT)
+            for key in ("energy", "virial", "lj", "real", "recip", "self"):
+                assert rel(tot[r][key], to[key]) < TOL, (r, key)
+
+
+def test_batch_parts_agree(orc):
+    """The split of a move over 1..16 workgroups changes only the summation order."""
+    a = common.nist_arrays(4, "unwrapped")
+    g = common.golden(4, "unwrapped")
+    mv = g["moves"][0]
+    ref = None
+    for parts in (1, 2, 3, 5, 9, 16):
+        with make_batch(a, 2) as b:
+            b.set_parts(parts)
+            b.recip_long()
+            d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (2, 1)),
+                           np.tile(np.array(mv["atoms_new"]).ravel(), (2, 1)))
+            assert np.array_equal(d[0], d[1])
+            if ref is None:
+                ref = d[0]
+            assert np.abs(d[0] - ref).max() < 1e-9 * 1e4
+            assert np.abs(d[0] - np.array(mv["d"])).max() < 1e-9 * 1e4
+
+
+def test_batch_per_replica_configs(orc):
+    """set_replica: replicas holding different configurations are evaluated independently."""
+    a1 = common.nist_arrays(1, "reference")
+    a2 = common.nist_arrays(1, "unwrapped")
+    with make_batch(a1, 4) as b:
+        b.set_replica(2, a2["com"], a2["coords"])
+        t = b.potential_ewald()
+        g1 = common.golden(1, "reference")["totals_ewald"]
+        g2 = common.golden(1, "unwrapped")["totals_ewald"]
+        for r, gg in ((0, g1), (1, g1), (2, g2), (3, g1)):
+            assert rel(t[r]["energy"], gg["energy"]) < TOL and rel(t[r]["real"], gg["real"]) < TOL
+
+
+def test_batch_errors():
+    from metropolismontecarlo_amd._lib import MMCError
+    a = common.nist_arrays(1)
+    with make_batch(a, 2) as b:
+        b.recip_long()
+        with pytest.raises(MMCError, match="MMC_ERR_ARG"):
+            b.eval(0, np.zeros((2, 3)), np.zeros((2, 9)))
+        with pytest.raises(MMCError, match="MMC_ERR_ARG"):
+            b.eval(101, np.zeros((2, 3)), np.zeros((2, 9)))
+        b.eval(5, np.tile(a["com"][4], (2, 1)), np.tile(a["coords"][12:15].ravel(), (2, 1)))
+        with pytest.raises(MMCError, match="MMC_ERR_STATE"):
+            b.get_replica(0)          # proposals outstanding
+        b.settle([0, 0])
+        b.get_replica(0)
+    with pytest.raises(AssertionError, match="nk == 5"):
+        make_batch(a, 1, nk=4)
+    bad = dict(a)
+    bad["coords"] = a["coords"][:-1]
+    with pytest.raises(AssertionError, match="n == 3"):
+        make_batch(bad, 1)
+
+
+@pytest.mark.parametrize("R,groups,parts", [(1, 1, 0), (5, 2, 0), (16, 3, 1), (8, 2, 4)])
+def test_engine_running_total_vs_recompute(R, groups, parts, orc):
+    """The reference's only integration invariant (Poly/main.jl:232-235): the running total
+    energy (initial + accepted deltas) equals a full recompute -- here after hundreds of native
+    driver steps, which also proves that commits reached the device coordinates and that the
+    incrementally updated S(k) still matches a fresh RecipLong."""
+    a = common.nist_arrays(1, "unwrapped")
+    n_steps = 260  # > 2 sweeps of 100 molecules: every molecule is proposed several times
+    with make_batch(a, R) as b:
+        t0 = b.potential_ewald()
+        e0 = np.array([t["energy"] for t in t0])
+        e1, st = b.run(n_steps, 298.15, 0.316555789, 0.05, seed=11234, energies=e0,
+                       n_groups=groups, n_parts=parts)
+        assert st["moves"] == n_steps * R
+        assert st["trans_attempt"] + st["rot_attempt"] == n_steps * R
+        acc = st["trans_accept"] + st["rot_accept"]
+        assert 0.2 * n_steps * R < acc < n_steps * R      # sane acceptance at 298 K
+        S_inc = [b.get_replica(r)[2] for r in range(R)]
+        t1 = b.potential_ewald()                          # refreshes S(k) from scratch
+        for r in range(R):
+            assert rel(e1[r], t1[r]["energy"]) < 1e-9, (r, e1[r], t1[r]["energy"])
+            S_new = b.get_replica(r)[2]
+            assert np.abs(S_inc[r] - S_new).max() < 1e-9 * np.abs(S_new).max()
+        if R > 1:  # independent RNG streams: replicas must have diverged
+            assert len({round(x, 6) for x in e1}) > 1
+        # and the device state is what the oracle says about it
+        com, coords, _ = b.get_replica(R - 1)
+        s = common.oracle_system(dict(a, com=com, coords=coords))
+        to = orc.potential_ewald(s, orc.Ewald(5.6 / s.box, 5, 27, s.box), RCUT, RCUT)
+        assert rel(t1[R - 1]["energy"], to["energy"]) < TOL
+
+
+def test_engine_deterministic_and_group_independent():
+    a = common.nist_arrays(1, "unwrapped")
+    res = []
+    for groups, parts in ((1, 1), (3, 1), (2, 5)):
+        with make_batch(a, 6) as b:
+            b.recip_long()
+            e, st = b.run(150, 298.15, 0.316555789, 0.05, seed=7, n_groups=groups, n_parts=parts)
+            res.append((e, st))
+    # same workgroup split -> bitwise identical whatever the stream grouping
+    assert np.array_equal(res[0][0], res[1][0])
+    for key in ("trans_accept", "rot_accept", "overlaps"):
+        assert res[0][1][key] == res[1][1][key]
+    # different split: same chain unless a Metropolis draw lands within rounding of the threshold
+    assert np.allclose(res[0][0], res[2][0], rtol=0, atol=1e-6)
+
+
+def test_engine_molecules_stay_rigid():
+    """Translations carry the atoms with the centre of mass through the periodic wrap and
+    rotations are rigid: intramolecular distances are conserved over a run."""
+    a = common.nist_arrays(2, "unwrapped")
+
+    def bonds(c):
+        c = c.reshape(-1, 3, 3)
+        return np.stack([np.linalg.norm(c[:, 0] - c[:, 1], axis=1),
+                         np.linalg.norm(c[:, 0] - c[:, 2], axis=1),
+                         np.linalg.norm(c[:, 1] - c[:, 2], axis=1)])
+
+    with make_batch(a, 2) as b:
+        b.recip_long()
+        b.run(600, 298.15, 0.316555789, 0.05, seed=3)
+        com, coords, _ = b.get_replica(1)
+        assert np.abs(bonds(coords) - bonds(a["coords"])).max() < 1e-9
+        assert (com >= 0).all() and (com <= a["box"]).all()   # PBC (boundaries.jl:16-26)
+        assert np.abs(coords - a["coords"]).max() > 1e-3        # something moved
