@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py -- MC trial moves/s of the per-move energy hot path on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W [--replicas R]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1]/[2]): SPC/E water, 750 molecules (NIST sample configuration 4 ==
+Ewald/coord750.txt, committed as tests/golden/spce_nist.npz), NVT at 298.15 K, full Ewald
+(kappa = 5.6/L, 337 k-vectors), fp64, r_cut = 10 A.  R independent replicas per GPU (one Markov
+chain each, RNG stream seed 11234 + global replica index); replicas shard across ranks with no
+data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of every
+replica of the rank: one fused launch of k_move_eval (2x LJ_poly_dU + 2x EwaldShort + RecipMove +
+commit of the previous accepted move) per replica group, followed by the sequential Metropolis
+accept/reject on the host (native C++ driver, mmc_batch_run).  Inputs are resident in HBM before
+the timed region; per step only the proposals (104 B per replica) travel to the device.
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline      dominant kernel k_move_eval: algorithmic bytes per launch (SURVEY.md section 8d:
+                78.7 KB per trial move at 750 molecules x replicas per launch) / average launch
+                duration measured with HIP events on the kernel's own stream inside the timed
+                region, against the 8 TB/s HBM peak.
+  cpu_baseline  the CPU oracle (a single-threaded C port of the reference's Julia code path; the
+                Julia reference itself cannot run here) timed on this host on the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+TEMPERATURE = 298.15      # Ewald/main.jl:62
+DR_MAX = 0.316555789      # Ewald/main.jl:118
+DPHI_MAX = 0.05           # Ewald/main.jl:73
+RCUT = 10.0               # Ewald/main.jl:67
+SEED = 11234              # Monatomic/mainMonatomic.jl:15
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+N_K = 337
+
+
+def algorithmic_bytes_per_move(n_mol, box, r_cut=RCUT, n_k=N_K):
+    """B_move = 2*(24*N_mol + 108*Mbar) + 52*N_k with
+    Mbar = 4/3 pi r_cut^3 * N_mol / L^3."""
+    mbar = 4.0 / 3.0 * np.pi * r_cut ** 3 * n_mol / box ** 3
+    return 2 * (24 * n_mol + 108 * mbar) + 52 * n_k
+
+
+def algorithmic_bytes_full_eval(n_mol, n_k=N_K):
+    """B_full = 36*N + 24*N_mol + 36*N_k."""
+    return 36 * 3 * n_mol + 24 * n_mol + 36 * n_k
+
+
+def cpu_baseline(a, budget_s):
+    """Time the oracle (C port, 1 thread) on the same workload: Loop()'s hot-path calls for
+    successive molecules with small rigid translations, for about `budget_s` seconds."""
+    import common
+    from oracle import oracle as orc
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    rng = np.random.default_rng(SEED)
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        i = n % s.n_mol + 1
+        d = (rng.random(3) - 0.5) * DR_MAX
+        cn = s.com[i - 1] + d
+        an = s.coords[3 * (i - 1):3 * i] + d
+        orc.trial_move(i, s, ew, RCUT, RCUT, cn, an)
+        ew.sumQExpNew[:] = ew.sumQExpOld  # reject: main.jl:628
+        n += 1
+        if n % 50 == 0 and time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    orc.potential_ewald(s, ew, RCUT, RCUT)
+    t_full = time.perf_counter() - t1
+    return n / dt, n, dt, t_full
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=600)
+    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
+    ap.add_argument("--groups", type=int, default=4, help="replica groups pipelined per GPU")
+    ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
+    ap.add_argument("--threads", type=int, default=4, help="host threads driving the groups")
+    ap.add_argument("--kernel", type=int, default=1, help="1 = LDS-tiled kernel, 0 = generic")
+    ap.add_argument("--zero-copy-moves", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-events", action="store_true",
+                    help="do not bracket launches with HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import common
+    from metropolismontecarlo_amd import sharding, structs
+    from metropolismontecarlo_amd.device import Batch
+
+    a = common.nist_arrays(4, "unwrapped")
+    n_mol, box = a["com"].shape[0], a["box"]
+    R = args.replicas
+    b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
+              5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
+    b.set_option("kernel", args.kernel)
+    b.set_option("zero_copy_moves", args.zero_copy_moves)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # initial total energy of every replica (also initialises S(k)): the M2 metric
+    b.potential_ewald()
+    barrier()
+    t0 = time.perf_counter()
+    tot = b.potential_ewald()
+    t_full = time.perf_counter() - t0
+    energies = np.array([t["energy"] for t in tot])
+    e_start = energies.copy()
+
+    # chain r of this rank has global index rank*R + r and draws from stream seed + r (the driver
+    # adds r): trajectories depend on the global index only, not on the number of GPUs
+    g0 = sharding.shard(R, rank)[0]
+    ev = 0 if args.no_events else 1
+    energies, _ = b.run(args.warmup, TEMPERATURE, DR_MAX, DPHI_MAX,
+                        sharding.replica_seed(g0, phase=0), energies,
+                        n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
+                        n_threads=args.threads)
+    barrier()
+    t0 = time.perf_counter()
+    energies, st = b.run(args.steps, TEMPERATURE, DR_MAX, DPHI_MAX,
+                         sharding.replica_seed(g0, phase=1), energies,
+                         n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
+                         n_threads=args.threads)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # consistency: running totals vs a full recompute (Poly/main.jl:232-235), outside the timing
+    tot2 = b.potential_ewald()
+    drift = float(np.max(np.abs(energies - np.array([t["energy"] for t in tot2]))
+                         / np.abs(energies)))
+
+    # C1: the only collective -- max of the time, sums of the observables (RCCL all-reduce)
+    local = dict(moves=st["moves"], accepted=st["trans_accept"] + st["rot_accept"],
+                 overlaps=st["overlaps"], energy_sum=float(energies.sum()),
+                 kernel_ms=st["kernel_ms"], launches=st["launches"])
+    d = dist if world > 1 else None
+    red, elapsed_max = sharding.reduce_observables(local, elapsed, d, device="cuda")
+    _, t_full_max = sharding.reduce_observables(local, t_full, d, device="cuda")
+    total_moves = red["moves"]
+
+    if rank == 0:
+        bytes_move = algorithmic_bytes_per_move(n_mol, box)
+        launches = st["launches"]
+        replicas_per_launch = st["moves"] / max(launches, 1)
+        out = {
+            "metric": "MC trial moves/sec (whole node), SPC/E NVT full Ewald fp64",
+            "value": total_moves / elapsed_max,
+            "unit": "moves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_max / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic: NIST SPC/E sample configuration 4 (750 molecules, L=30 A) "
+                    "replicated; random trial moves",
+            "config": {"workload": "SPC/E 750 molecules NVT 298.15 K, full Ewald (337 k), "
+                                   "r_cut 10 A, independent replicas",
+                       "replicas_per_gpu": R, "replicas_total": R * world,
+                       "groups_per_gpu": args.groups, "parallelism": f"replicas x{world}"},
+            "acceptance": red["accepted"] / max(total_moves, 1),
+            "overlaps": int(red["overlaps"]),
+            "energy_mean_per_replica": red["energy_sum"] / (R * world),
+            "energy_drift_rel": drift,
+            "ns_per_full_energy_eval": 1e9 * t_full_max / R,
+            "full_energy_evals_per_s": R * world / t_full_max,
+        }
+        if ev and launches:
+            t_launch = st["kernel_ms"] * 1e-3 / launches  # rank 0's average launch duration
+            achieved = bytes_move * replicas_per_launch / t_launch / 1e9
+            out["roofline"] = {
+                "kernel": "k_move_eval", "bound": "hbm", "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_launch_us": 1e6 * t_launch, "launches": int(launches),
+                "algorithmic_bytes_per_move": bytes_move,
+                "moves_per_launch": replicas_per_launch,
+                "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+            }
+        if not args.no_cpu:
+            mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
+            out["cpu_baseline"] = {
+                "value": mps, "unit": "moves/s", "cores": 1, "kind": "port",
+                "sample": f"{n} trial moves (2x LJ_poly_dU + 2x EwaldShort + RecipMove) of the "
+                          f"same 750-molecule system in {dt:.1f} s, C oracle, 1 thread",
+                "ns_per_full_energy_eval": 1e9 * tf,
+            }
+        print(json.dumps(out))
+    b.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

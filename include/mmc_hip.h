@@ -78,7 +78,8 @@ int32_t mmc_upload_system(mmc_ctx *ctx, int64_t n_mol, int64_t n_atoms, const do
  * device-side counterpart of those two assignments.  `atoms`: 3*(last-first+1) doubles. */
 int32_t mmc_set_molecule(mmc_ctx *ctx, int64_t i, const double *com, const double *atoms);
 /* Re-send every centre of mass and atom position (same topology): the whole-array form of the
- * assignments above, for callers that changed more than one molecule on the host. */
+ * assignments above, for callers that changed more than one molecule on the host.  `com` may be
+ * NULL to re-send the atoms only (all that RecipLong reads). */
 int32_t mmc_update_system(mmc_ctx *ctx, const double *com, const double *coords);
 int32_t mmc_download_system(mmc_ctx *ctx, double *com, double *coords);
 
@@ -191,6 +192,16 @@ int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *res
 /* Workgroups per replica-move used by mmc_batch_eval (1..16; 1 = one workgroup does the whole
  * move, >1 = the molecule range is split and the last workgroup does the reciprocal part). */
 int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
+/* Tuning switches (no effect on results beyond summation order):
+ *   "parts"            as mmc_batch_set_parts
+ *   "kernel"           1 = LDS-tiled kernel with the erfc(kappa r)/r table (default when every
+ *                      molecule has the same atom types and charges), 0 = generic kernel
+ *   "zero_copy_moves"  1 = the kernel reads proposals from pinned host memory instead of an
+ *                      H2D copy on the stream (lower latency for one replica, default 0) */
+int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
+/* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
+ * r^2 in (0, 1024): lets a test bound its error against an exact evaluation. */
+int32_t mmc_batch_qq_table(mmc_batch *b, const double *r2, int64_t n, double *out);
 /* Settle the last outstanding proposals without evaluating new ones. */
 int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
 
@@ -206,7 +217,7 @@ typedef struct {
     int32_t n_groups;    /* replica groups pipelined on separate streams (>=1) */
     int32_t n_parts;     /* workgroups per replica-move (0 = choose) */
     int32_t time_kernels;/* 1: bracket every launch with HIP events (stats.kernel_ms) */
-    int32_t _pad;
+    int32_t n_threads;   /* host threads sharing the groups (0 or 1 = the calling thread only) */
 } mmc_run_params;
 
 typedef struct {

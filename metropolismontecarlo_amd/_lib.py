@@ -47,7 +47,7 @@ class RunParams(C.Structure):
     """mmc_run_params"""
     _fields_ = [("temperature", C.c_double), ("dr_max", C.c_double), ("dphi_max", C.c_double),
                 ("seed", C.c_uint64), ("n_steps", C.c_int64), ("n_groups", C.c_int32),
-                ("n_parts", C.c_int32), ("time_kernels", C.c_int32), ("_pad", C.c_int32)]
+                ("n_parts", C.c_int32), ("time_kernels", C.c_int32), ("n_threads", C.c_int32)]
 
 
 class RunStats(C.Structure):
@@ -106,6 +106,8 @@ SIGNATURES = {
     "mmc_batch_potential_ewald": [_vp, C.POINTER(Totals)],
     "mmc_batch_eval": [_vp, C.POINTER(Move), C.POINTER(MoveResult)],
     "mmc_batch_set_parts": [_vp, _i32],
+    "mmc_batch_set_option": [_vp, C.c_char_p, _i64],
+    "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
 }

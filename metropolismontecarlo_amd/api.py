@@ -56,7 +56,7 @@ class _Session:
         self.box = float(box)
         self.last_mol = None
         self.ewald_key = None
-        self.s_ids = (None, None)  # identity of the host arrays the device S mirrors
+        self.s_ids = (None, None)  # host copies of what the device S buffers hold
         self.moa = weakref.ref(moa)
         self._soa_coords_id = id(soa.coords)
 
@@ -81,18 +81,24 @@ class _Session:
         ewald._session = self
 
     def push_s(self, ewald):
-        """Send sumQExpOld/New if the caller rebound or never sent them."""
-        ids = (id(ewald.sumQExpOld), id(ewald.sumQExpNew))
-        if ids != self.s_ids and len(ewald.sumQExpOld) == self.ctx.nkvecs:
-            self.ctx.set_sumqexp(ewald.sumQExpOld, ewald.sumQExpNew)
-            self.s_ids = ids
+        """Send sumQExpOld/New when the host arrays differ from what the device holds (Loop
+        rebinds them to copies, main.jl:621,628).  Compared by CONTENT -- 337 complex numbers --
+        because object identity can be recycled by the allocator."""
+        so = np.asarray(ewald.sumQExpOld, dtype=np.complex128)
+        sn = np.asarray(ewald.sumQExpNew, dtype=np.complex128)
+        if len(so) != self.ctx.nkvecs or len(sn) != self.ctx.nkvecs:
+            return
+        m = self.s_ids
+        if m[0] is None or not (np.array_equal(so, m[0]) and np.array_equal(sn, m[1])):
+            self.ctx.set_sumqexp(so, sn)
+            self.s_ids = (so.copy(), sn.copy())
 
     def pull_s(self, ewald, old=False):
         so, sn = self.ctx.get_sumqexp()
         if old:
             ewald.sumQExpOld = so
         ewald.sumQExpNew = sn
-        self.s_ids = (id(ewald.sumQExpOld), id(ewald.sumQExpNew))
+        self.s_ids = (so.copy(), sn.copy())
 
 
 _sessions = {}
@@ -291,7 +297,7 @@ def RecipCommit(ewald):
     s = ewald._session
     s.ctx.recip_commit()
     ewald.sumQExpOld = ewald.sumQExpNew.copy()
-    s.s_ids = (id(ewald.sumQExpOld), id(ewald.sumQExpNew))
+    s.s_ids = (ewald.sumQExpOld.copy(), ewald.sumQExpNew.copy())
 
 
 def RecipRollback(ewald):
@@ -299,7 +305,7 @@ def RecipRollback(ewald):
     s = ewald._session
     s.ctx.recip_rollback()
     ewald.sumQExpNew = ewald.sumQExpOld.copy()
-    s.s_ids = (id(ewald.sumQExpOld), id(ewald.sumQExpNew))
+    s.s_ids = (ewald.sumQExpOld.copy(), ewald.sumQExpNew.copy())
 
 
 def EwaldSelf(ewald, qq_q):

@@ -115,6 +115,39 @@ __device__ __forceinline__ void block_sum(const double (&v)[NV], double *red, do
     __syncthreads();
 }
 
+// The same sum for many values at once, through an LDS transpose instead of NV separate 64-lane
+// shuffle trees: every thread parks its NV partials, then NV*32 threads each add 8 of them
+// (unit-stride, conflict-free) and a 32-lane tree finishes one value per half-wave.  About 4x
+// fewer LDS operations than block_sum for NV = 7.  buf: NV*256 doubles of LDS; res: NV doubles of
+// LDS (thread 0 reads the totals from it after the call).  `flag` (0/1 per thread) is OR-reduced
+// over the workgroup into *flag_out for free.  Fixed order -> bitwise reproducible.
+template <int NV>
+__device__ __forceinline__ void block_sum_wide(const double (&v)[NV], double *buf, double *res,
+                                               int flag, int32_t *wflag)
+{
+#pragma unroll
+    for (int k = 0; k < NV; k++)
+        buf[k * MMC_BLOCK + threadIdx.x] = v[k];
+    const unsigned long long b0 = __ballot((flag & 1) != 0), b1 = __ballot((flag & 2) != 0);
+    if (lane_id() == 0)
+        wflag[wave_id()] = (b0 != 0ULL ? 1 : 0) | (b1 != 0ULL ? 2 : 0);
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < NV * 32) { // NV <= 8
+        const int k = t >> 5, c = t & 31;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < MMC_BLOCK / 32; i++)
+            s += buf[k * MMC_BLOCK + i * 32 + c];
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1)
+            s += __shfl_down(s, off, 32);
+        if (c == 0)
+            res[k] = s;
+    }
+    __syncthreads();
+}
+
 // STYLE 0: erfc-damped Coulomb (EwaldReal); STYLE 1: bare Coulomb (CoulombReal).
 //
 // Scan molecules [j_begin, j_end) of replica `s` against the chosen molecule in NS states.

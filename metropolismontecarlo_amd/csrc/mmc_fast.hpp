@@ -1,0 +1,498 @@
+// mmc_fast.hpp -- the production form of the per-move kernel (K1+K4) for the replica batch.
+//
+// Same results as k_move_eval (mmc_kernels.hpp), restructured around what rocprofv3 showed for it
+// (profiles/round1_*): one workgroup per replica-move was latency- and occupancy-bound -- 189
+// VGPRs (2 waves/SIMD), ~8 dependent memory round trips per workgroup (70 % of wave cycles in
+// SQ_WAIT_ANY), move records read over PCIe, ocml erfc with 4 divergent ranges.
+//
+//   * topology is HOMOGENEOUS (every molecule has the same 3 atom types/charges, true for any
+//     pure rigid-water system): neighbour types/charges/LJ parameters are launch constants,
+//     no per-neighbour index loads;
+//   * TWO memory round trips per workgroup.  Trip 1, issued together at entry: the move record
+//     (which carries the chosen molecule's OLD and NEW coordinates, so nothing depends on it),
+//     the first centres of mass of the COM scan, the erfc table, the k-vector constants.
+//     Trip 2: the gather of the surviving neighbours' 96-byte records (atoms + COM) into an LDS
+//     tile by 6 lanes x 16 B each ("LDS-staged neighbour tiles"), issued into registers and
+//     overlapped with the reciprocal-space arithmetic; the pair loops then read LDS only;
+//   * one lane per (neighbour, atom pair a-b): 9 lanes per neighbour, both states;
+//   * erfc(kappa r)/r comes from a piecewise degree-10 polynomial in r^2, 16 pieces per octave
+//     over r^2 in [0.25, 256), selected by the exponent/mantissa bits of r^2: no sqrt, no
+//     division, no erfc in the loop.  The table (14 KB) is built once per kappa on the device
+//     from ocml erfc/sqrt at Chebyshev nodes; its error against exact arithmetic (<= 5e-15
+//     relative for kappa*r <= 4) is the conditioning error of erfc(kappa*sqrt(r2)) in fp64, i.e.
+//     the same as the reference's own direct evaluation (tests/test_gpu_table.py);
+//   * LJ terms (only atom pairs with eps > 0.001, energy.jl:270) run as a second compacted pass;
+//   * move records are read from device memory (copied H2D on the stream), results are written
+//     straight to pinned host memory.
+//
+// Branch decisions (gates, overlap, slack) still use the reference's exact comparisons on
+// unfused arithmetic, so neighbour lists and overlap flags are bit-identical to the oracle's.
+#pragma once
+#include "mmc_kernels.hpp"
+
+#define MMC_TILE 150      // neighbours staged per LDS tile (14 KB; doubles as reduction scratch)
+#define MMC_REC 12        // doubles per molecule record: 9 atom coordinates + 3 COM
+#define MMC_QQ_DEG 10
+#define MMC_QQ_NCOEF (MMC_QQ_DEG + 1)
+#define MMC_QQ_NINT 160   // 10 octaves [2^-2, 2^8) x 16 sub-intervals
+#define MMC_QQ_UMIN 0.25
+#define MMC_QQ_UMAX 256.0    // the host selects this kernel only if r_cut^2 + 100 <= UMAX,
+#define MMC_QQ_XMAX 4.0      // kappa * sqrt(r_cut^2 + 100) <= XMAX (degree 10 is enough there)
+#define MMC_QQ_KAPPA_MAX 0.5 // and kappa <= this (the series below UMIN needs kappa*r <= 0.25)
+#define MMC_FLIST_CAP 768
+#define MMC_PRE 2            // COM-scan iterations whose loads are issued at kernel entry
+                             // (3 would cost 10 more VGPRs and the 4th wave per SIMD)
+#define MMC_GATHER_REGS ((MMC_TILE * 6 + MMC_BLOCK - 1) / MMC_BLOCK)
+
+// word offsets (8 B) inside a MoveRec
+#define MV_COM_NEW 1
+#define MV_AT_NEW 4
+#define MV_COM_OLD 13
+#define MV_AT_OLD 16
+#define MV_WORDS 25
+static_assert(sizeof(MoveRec) == MV_WORDS * 8, "MoveRec layout");
+static_assert(MMC_TILE * MMC_REC >= 7 * MMC_BLOCK, "the tile doubles as reduction scratch");
+
+// Launch constants of a homogeneous system (built on the host once, mmc_batch_create).
+struct FastConsts {
+    double qq9[9];             // q_a * q_b
+    double ljp_eps[9], ljp_sig[9];
+    int32_t ljp_ab[9];         // atom pairs (3a + b) with eps > 0.001 (energy.jl:270)
+    int32_t n_ljp;
+    double q[3];
+};
+
+// f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t in [-1, 1).
+__device__ __forceinline__ double qq_table_eval(const double *tab, double u)
+{
+    const long long bits = __double_as_longlong(u);
+    const int idx = (int)(bits >> 48) - 0x3FD0; // exponent + top 4 mantissa bits, 0 at u = 0.25
+    const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
+    const double d = __longlong_as_double(lo | 0x3FF0000000000000LL); // [1, 2): position in piece
+    const double t = 2.0 * d - 3.0;
+    const double *c = tab + idx * MMC_QQ_NCOEF;
+    double acc = c[MMC_QQ_DEG];
+#pragma unroll
+    for (int j = MMC_QQ_DEG - 1; j >= 0; j--)
+        acc = fma(acc, t, c[j]);
+    return acc;
+}
+
+// u < UMIN happens only for like charges closer than 0.5 A (opposite charges that close are
+// overlaps).  There x = kappa*r <= 0.25 and the Maclaurin series of erf needs 9 terms for 1e-16:
+// erfc(x)/r = 1/r - (2 kappa/sqrt(pi)) * sum_n (-1)^n x^(2n) / (n! (2n+1)).
+__device__ __forceinline__ double qq_pair(const double *tab, double u, double kappa)
+{
+    if (u >= MMC_QQ_UMIN)
+        return qq_table_eval(tab, u);
+    const double x2 = kappa * kappa * u;
+    double p = 1.0 / (40320.0 * 17.0);
+    p = fma(p, -x2, 1.0 / (5040.0 * 15.0));
+    p = fma(p, -x2, 1.0 / (720.0 * 13.0));
+    p = fma(p, -x2, 1.0 / (120.0 * 11.0));
+    p = fma(p, -x2, 1.0 / (24.0 * 9.0));
+    p = fma(p, -x2, 1.0 / (6.0 * 7.0));
+    p = fma(p, -x2, 1.0 / (2.0 * 5.0));
+    p = fma(p, -x2, 1.0 / 3.0);
+    p = fma(p, -x2, 1.0);
+    return rsqrt(u) - 1.1283791670955126 * kappa * p; // 2/sqrt(pi)
+}
+
+// Build the table: one thread per piece.  Chebyshev interpolation at 11 nodes of the exact
+// (ocml) function, converted to the monomial basis in t for Horner evaluation.
+__global__ void k_build_qq_table(double kappa, double *tab)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= MMC_QQ_NINT)
+        return;
+    const int e = idx / 16 - 2, k = idx % 16;
+    const double ua = ldexp(1.0 + k / 16.0, e), ub = ldexp(1.0 + (k + 1) / 16.0, e);
+    const double uc = 0.5 * (ua + ub), uh = 0.5 * (ub - ua);
+    const int N = MMC_QQ_NCOEF;
+    double f[MMC_QQ_NCOEF], c[MMC_QQ_NCOEF];
+    for (int n = 0; n < N; n++) {
+        const double x = cos(3.141592653589793 * (n + 0.5) / N);
+        const double u = uc + x * uh, r = sqrt(u);
+        f[n] = erfc(kappa * r) / r;
+    }
+    for (int j = 0; j < N; j++) {
+        double s = 0.0;
+        for (int n = 0; n < N; n++)
+            s += f[n] * cos(3.141592653589793 * j * (n + 0.5) / N);
+        c[j] = s * (j == 0 ? 1.0 : 2.0) / N;
+    }
+    // Chebyshev -> monomial: T0 = 1, T1 = t, T_{j+1} = 2 t T_j - T_{j-1}
+    double m[MMC_QQ_NCOEF], tp[MMC_QQ_NCOEF], tc[MMC_QQ_NCOEF], tn[MMC_QQ_NCOEF];
+    for (int j = 0; j < N; j++) { m[j] = 0.0; tp[j] = 0.0; tc[j] = 0.0; }
+    tp[0] = 1.0; // T0
+    tc[1] = 1.0; // T1
+    m[0] += c[0];
+    for (int j = 0; j < N; j++)
+        m[j] += c[1] * tc[j];
+    for (int d = 2; d < N; d++) {
+        for (int j = 0; j < N; j++)
+            tn[j] = (j > 0 ? 2.0 * tc[j - 1] : 0.0) - tp[j];
+        for (int j = 0; j < N; j++) {
+            m[j] += c[d] * tn[j];
+            tp[j] = tc[j];
+            tc[j] = tn[j];
+        }
+    }
+    for (int j = 0; j < N; j++)
+        tab[idx * N + j] = m[j];
+}
+
+// Evaluate the erfc(kappa r)/r approximation at arbitrary r^2 (accuracy tests, mmc_batch_qq_table).
+__global__ void k_eval_qq_table(const double *tab, double kappa, const double *u, double *out,
+                                int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        out[i] = qq_pair(tab, u[i], kappa);
+}
+
+// rec[r][j][0..8] = atoms of molecule j (x0 y0 z0 x1 ... z2), rec[r][j][9..11] = COM.
+__global__ void k_build_rec(BatchView bv, double *rec, int r)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= bv.n_mol)
+        return;
+    double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_REC;
+    const int64_t a0 = r * bv.atom_stride + bv.first0[j], m0 = r * bv.mol_stride + j;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        o[3 * a] = bv.ax[a0 + a]; o[3 * a + 1] = bv.ay[a0 + a]; o[3 * a + 2] = bv.az[a0 + a];
+    }
+    o[9] = bv.comx[m0]; o[10] = bv.comy[m0]; o[11] = bv.comz[m0];
+}
+
+__global__ void k_broadcast_rec(double *rec, int64_t per_replica)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y + 1;
+    if (i < per_replica)
+        rec[r * per_replica + i] = rec[i];
+}
+
+// k-vector constants packed for one load per k: kx | (ky+5) << 4 | (kz+5) << 8
+__global__ void k_pack_kvec(const int32_t *kxyz, int n, int32_t *kpack)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n)
+        kpack[k] = kxyz[3 * k] | ((kxyz[3 * k + 1] + 5) << 4) | ((kxyz[3 * k + 2] + 5) << 8);
+}
+
+struct FastShared {
+    alignas(16) double tile[MMC_TILE * MMC_REC]; // neighbour records, written as double2
+    alignas(16) double mvw[MV_WORDS + 1];        // this replica's move record
+    alignas(16) double pvw[MV_WORDS + 1];        // its previous move record (pending commit)
+    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    cplx ptab[2][3][3][MMC_NKTAB];
+    double red[7 * MMC_WAVES];
+    double qq9[9], ljp_eps[9], ljp_sig[9];
+    int32_t list[MMC_FLIST_CAP];
+    int32_t tflag[MMC_TILE];
+    int32_t ljp_ab[9];
+    int32_t wcnt[MMC_WAVES];
+};
+
+// grid (n_parts, replicas of the group); same part semantics as k_move_eval.
+__global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
+    BatchView bv, double *rec, const double *qq_tab, const int32_t *kpack, FastConsts fc,
+    const MoveRec *cur, const MoveRec *prev, PartOut *out, int n_parts, PairParams pp, int r_base)
+{
+    __shared__ __align__(16) FastShared sm;
+
+    const int r = r_base + blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
+    const int n_mol = bv.n_mol;
+    const double box = bv.box;
+    const double *comx = bv.comx + r * bv.mol_stride, *comy = bv.comy + r * bv.mol_stride,
+                 *comz = bv.comz + r * bv.mol_stride;
+    double *myrec = rec + (int64_t)r * n_mol * MMC_REC;
+    const bool do_pairs = (n_parts == 1) || (part < n_parts - 1);
+    const bool do_recip = (n_parts == 1) || (part == n_parts - 1);
+    const int np = (n_parts == 1) ? 1 : n_parts - 1;
+    const int plen = (n_mol + np - 1) / np;
+    const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
+    const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0; // >= j_begin
+    const int w = wave_id();
+
+    // ================= trip 1: everything that depends on nothing =================
+    if (tid < MV_WORDS)
+        sm.mvw[tid] = reinterpret_cast<const double *>(cur + r)[tid];
+    else if (prev && tid >= 32 && tid < 32 + MV_WORDS)
+        sm.pvw[tid - 32] = reinterpret_cast<const double *>(prev + r)[tid - 32];
+    else if (tid >= 64 && tid < 73) {
+        const int t = tid - 64;
+        sm.qq9[t] = fc.qq9[t];
+        sm.ljp_eps[t] = fc.ljp_eps[t];
+        sm.ljp_sig[t] = fc.ljp_sig[t];
+        sm.ljp_ab[t] = fc.ljp_ab[t];
+    }
+    if (do_pairs)
+        for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += MMC_BLOCK)
+            sm.qtab[k] = qq_tab[k];
+    // first centres of mass of this wave's share of the COM scan
+    const int len0 = min(MMC_FLIST_CAP, j_end - j_begin);
+    const int seg0 = ((len0 + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64;
+    // (the first MMC_PRE iterations of the scan: all of it for 750 molecules in one workgroup)
+    double pcx[MMC_PRE], pcy[MMC_PRE], pcz[MMC_PRE];
+    {
+        const int w0 = j_begin + w * seg0, w1 = min(w0 + seg0, j_begin + len0);
+#pragma unroll
+        for (int it = 0; it < MMC_PRE; it++) {
+            const int j = w0 + it * 64 + lane_id();
+            pcx[it] = pcy[it] = pcz[it] = 0.0;
+            if (do_pairs && j < w1) {
+                pcx[it] = comx[j]; pcy[it] = comy[j]; pcz[it] = comz[j];
+            }
+        }
+    }
+    int kp0 = 0, kp1 = 0;
+    double cf0 = 0.0, cf1 = 0.0;
+    if (do_recip) {
+        if (tid < bv.nkvecs) { kp0 = kpack[tid]; cf0 = bv.cfac[tid]; }
+        if (tid + MMC_BLOCK < bv.nkvecs) { kp1 = kpack[tid + MMC_BLOCK]; cf1 = bv.cfac[tid + MMC_BLOCK]; }
+    }
+    __syncthreads();
+
+    const int2 hdr = *reinterpret_cast<const int2 *>(&sm.mvw[0]);
+    const int i0 = hdr.x - 1, flags = hdr.y;
+    const bool commit = prev && (flags & 1);
+    const int scur = (flags >> 1) & 1;
+    const int pend = commit ? reinterpret_cast<const int *>(&sm.pvw[0])[0] - 1 : -1;
+    // pending commit in record layout: word t of [atoms_new(9), com_new(3)]
+    auto pd_word = [&](int t) { return sm.pvw[t < 9 ? MV_AT_NEW + t : MV_COM_NEW + (t - 9)]; };
+    // chosen molecule: st 0 = old (from the host's mirror), st 1 = proposal
+    auto ch_at = [&](int st, int a, int d) { return sm.mvw[(st ? MV_AT_NEW : MV_AT_OLD) + 3 * a + d]; };
+    auto ch_com = [&](int st, int d) { return sm.mvw[(st ? MV_COM_NEW : MV_COM_OLD) + d]; };
+
+    // commit of the previous accepted move (main.jl:598-621): written by one workgroup; every
+    // reader in this launch substitutes the pending words for that molecule.
+    if (part == 0 && commit && tid < 12) {
+        const double v = pd_word(tid);
+        myrec[(int64_t)pend * MMC_REC + tid] = v;
+        if (tid < 9) {
+            const int a = tid / 3, d = tid % 3;
+            (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + 3 * pend + a] = v;
+        } else {
+            const int d = tid - 9;
+            (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = v;
+        }
+    }
+    if (do_recip && tid >= 64 && tid < 82) { // phase tables of the 3 moved atoms, old and new
+        const int t = tid - 64;
+        const int st = t / 9, l = (t % 9) / 3, d = t % 3;
+        phase_row(ch_at(st, l, d), box, sm.ptab[st][l][d]);
+    }
+
+    double a_lj0 = 0, a_lj1 = 0, a_v0 = 0, a_v1 = 0, a_q0 = 0, a_q1 = 0, a_rec = 0;
+    int ovl0 = 0, ovl1 = 0;
+    // S(k) of the current buffer for this thread's k-vectors: issued now, consumed after the pair
+    // loops, so the round trip is hidden behind them
+    double so0r = 0, so0i = 0, so1r = 0, so1i = 0;
+    if (do_recip) {
+        const double *So = s_buf(bv, r, scur);
+        if (tid < bv.nkvecs) { so0r = So[2 * tid]; so0i = So[2 * tid + 1]; }
+        if (tid + MMC_BLOCK < bv.nkvecs) {
+            so1r = So[2 * (tid + MMC_BLOCK)]; so1i = So[2 * (tid + MMC_BLOCK) + 1];
+        }
+    }
+
+    if (do_pairs) {
+        const int n_ljp = fc.n_ljp;
+        for (int jb = j_begin; jb < j_end; jb += MMC_FLIST_CAP) {
+            const int je = min(jb + MMC_FLIST_CAP, j_end);
+            const int len = je - jb;
+            const int seg = ((len + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64;
+            const int wj0 = jb + w * seg, wj1 = min(wj0 + seg, je);
+            // ---- phase A: COM gates of both states, compact survivors (ascending j) ----
+            int count = 0;
+            auto gate_and_append = [&](int j, double cx, double cy, double cz) {
+                int f = 0;
+                if (j < wj1 && j != i0) {
+                    if (j == pend) { cx = pd_word(9); cy = pd_word(10); cz = pd_word(11); }
+#pragma unroll
+                    for (int st = 0; st < 2; st++) {
+                        const double dx = vector1D(ch_com(st, 0), cx, box);
+                        const double dy = vector1D(ch_com(st, 1), cy, box);
+                        const double dz = vector1D(ch_com(st, 2), cz, box);
+                        const double r2 = dx * dx + dy * dy + dz * dz;
+                        f |= (r2 < pp.lj_gate_sq) ? (1 << st) : 0;       // energy.jl:254
+                        f |= (r2 < pp.qq_gate_sq) ? (4 << st) : 0;       // ewalds.jl:340
+                    }
+                }
+                const unsigned long long m = __ballot(f != 0);
+                if (f)
+                    sm.list[w * seg + count + lanes_below(m)] = j | (f << 27);
+                count += __popcll(m);
+            };
+            int base = wj0;
+            if (jb == j_begin) { // the prefetched iterations
+#pragma unroll
+                for (int it = 0; it < MMC_PRE; it++) {
+                    if (base < wj1) {
+                        gate_and_append(base + lane_id(), pcx[it], pcy[it], pcz[it]);
+                        base += 64;
+                    }
+                }
+            }
+            for (; base < wj1; base += 64) { // larger systems: plain loads
+                const int j = base + lane_id();
+                double cx = 0.0, cy = 0.0, cz = 0.0;
+                if (j < wj1) { cx = comx[j]; cy = comy[j]; cz = comz[j]; }
+                gate_and_append(j, cx, cy, cz);
+            }
+            if (lane_id() == 0)
+                sm.wcnt[w] = count;
+            __syncthreads();
+            const int c0 = sm.wcnt[0], c1 = sm.wcnt[1], c2 = sm.wcnt[2], c3 = sm.wcnt[3];
+            const int total = c0 + c1 + c2 + c3;
+
+            for (int t0 = 0; t0 < total; t0 += MMC_TILE) {
+                const int nt = min(MMC_TILE, total - t0);
+                // ---- trip 2: gather 6 lanes x 16 B per neighbour record -> LDS tile ----
+                for (int g = tid; g < nt * 6; g += MMC_BLOCK) {
+                    const int n = g / 6, piece = g - n * 6;
+                    const int pos = t0 + n;
+                    int slot;
+                    if (pos < c0) slot = pos;
+                    else if (pos < c0 + c1) slot = seg + (pos - c0);
+                    else if (pos < c0 + c1 + c2) slot = 2 * seg + (pos - c0 - c1);
+                    else slot = 3 * seg + (pos - c0 - c1 - c2);
+                    const int ent = sm.list[slot];
+                    const int j = ent & ((1 << 27) - 1);
+                    double2 v;
+                    if (j == pend) {
+                        v.x = pd_word(2 * piece);
+                        v.y = pd_word(2 * piece + 1);
+                    } else {
+                        v = *reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC +
+                                                               2 * piece);
+                    }
+                    *reinterpret_cast<double2 *>(&sm.tile[n * MMC_REC + 2 * piece]) = v;
+                    if (piece == 0)
+                        sm.tflag[n] = ent >> 27;
+                }
+                __syncthreads();
+                // ---- Coulomb pass: one lane per (neighbour, a, b), both states ----
+                for (int g = tid; g < nt * 9; g += MMC_BLOCK) {
+                    const int n = g / 9, ab = g - n * 9;
+                    const int a = ab / 3, b = ab - 3 * a;
+                    const int f = sm.tflag[n];
+                    const double bx = sm.tile[n * MMC_REC + 3 * b],
+                                 by = sm.tile[n * MMC_REC + 3 * b + 1],
+                                 bz = sm.tile[n * MMC_REC + 3 * b + 2];
+                    const double qq = sm.qq9[ab];
+#pragma unroll
+                    for (int st = 0; st < 2; st++) {
+                        if (f & (4 << st)) {
+                            const double rx = vector1D(ch_at(st, a, 0), bx, box);
+                            const double ry = vector1D(ch_at(st, a, 1), by, box);
+                            const double rz = vector1D(ch_at(st, a, 2), bz, box);
+                            const double rab2 = rx * rx + ry * ry + rz * rz;
+                            if ((rab2 < pp.ovr) && (qq < 0)) {          // ewalds.jl:359
+                                if (st == 0) ovl0 = 1; else ovl1 = 1;
+                            } else if (rab2 < pp.qq_slack_sq) {          // ewalds.jl:362
+                                const double e = qq * qq_pair(sm.qtab, rab2, pp.kappa);
+                                if (st == 0) a_q0 += e; else a_q1 += e;
+                            }
+                        }
+                    }
+                }
+                // ---- LJ pass: only atom pairs with eps > 0.001 ----
+                for (int g = tid; g < nt * n_ljp; g += MMC_BLOCK) {
+                    int n = g, p = 0;
+                    if (n_ljp != 1) { // water has one LJ pair (O-O): skip the integer division
+                        n = g / n_ljp;
+                        p = g - n * n_ljp;
+                    }
+                    const int ab = sm.ljp_ab[p];
+                    const int a = ab / 3, b = ab - 3 * a;
+                    const int f = sm.tflag[n];
+                    const double e = sm.ljp_eps[p], sg = sm.ljp_sig[p];
+                    const double *t = &sm.tile[n * MMC_REC];
+#pragma unroll
+                    for (int st = 0; st < 2; st++) {
+                        if (f & (1 << st)) {
+                            const double rx = vector1D(ch_at(st, a, 0), t[3 * b], box);
+                            const double ry = vector1D(ch_at(st, a, 1), t[3 * b + 1], box);
+                            const double rz = vector1D(ch_at(st, a, 2), t[3 * b + 2], box);
+                            const double rab2 = rx * rx + ry * ry + rz * rz;
+                            if (rab2 < pp.lj_slack_sq) {                 // energy.jl:270
+                                const double cx = vector1D(ch_com(st, 0), t[9], box);
+                                const double cy = vector1D(ch_com(st, 1), t[10], box);
+                                const double cz = vector1D(ch_com(st, 2), t[11], box);
+                                const double s2 = sg * sg / rab2;
+                                const double s6 = s2 * s2 * s2;
+                                const double s12 = s6 * s6;
+                                const double virab = e * (2.0 * s12 - s6);
+                                const double f0 = rx * virab * s2, f1 = ry * virab * s2,
+                                             f2 = rz * virab * s2;
+                                const double pe = e * (s12 - s6);
+                                const double pv = cx * f0 + cy * f1 + cz * f2;
+                                if (st == 0) { a_lj0 += pe; a_v0 += pv; }
+                                else { a_lj1 += pe; a_v1 += pv; }
+                            }
+                        }
+                    }
+                }
+                __syncthreads(); // the tile and the list are reused
+            }
+        }
+    }
+    // ---- reciprocal part for this thread's k-vectors (ewalds.jl:803-821) ----
+    if (do_recip) {
+        __syncthreads(); // ptab (a no-op cost-wise when the pair loops already synchronised)
+        double *Sn = s_buf(bv, r, scur ^ 1);
+#pragma unroll 1
+        for (int h = 0; h < 2; h++) {
+            const int k = tid + h * MMC_BLOCK;
+            if (k < bv.nkvecs) {
+                const int kp = h ? kp1 : kp0;
+                const double cf = h ? cf1 : cf0;
+                const double orr = h ? so1r : so0r, oi = h ? so1i : so0i;
+                const int kx = kp & 15, ky = (kp >> 4) & 15, kz = (kp >> 8) & 15;
+                double nr = orr, ni = oi;
+#pragma unroll 1
+                for (int l = 0; l < 3; l++) {
+                    const cplx tn = c_mul(c_mul(sm.ptab[1][l][0][5 + kx], sm.ptab[1][l][1][ky]),
+                                          sm.ptab[1][l][2][kz]);
+                    const cplx to = c_mul(c_mul(sm.ptab[0][l][0][5 + kx], sm.ptab[0][l][1][ky]),
+                                          sm.ptab[0][l][2][kz]);
+                    nr += fc.q[l] * (tn.re - to.re);
+                    ni += fc.q[l] * (tn.im - to.im);
+                }
+                Sn[2 * k] = nr; Sn[2 * k + 1] = ni;
+                a_rec += cf * ((nr * nr - (-ni) * ni) - (orr * orr - (-oi) * oi));
+            }
+        }
+    }
+
+    // one transpose-reduction for the seven sums and the two overlap flags; the tile is free now
+    __syncthreads();
+    double v[7] = { a_lj0, a_lj1, a_v0, a_v1, a_q0, a_q1, a_rec };
+    block_sum_wide<7>(v, sm.tile, sm.red, ovl0 | (ovl1 << 1), sm.wcnt);
+    if (tid == 0) {
+        const int of = sm.wcnt[0] | sm.wcnt[1] | sm.wcnt[2] | sm.wcnt[3];
+        PartOut po;
+        po.lj_pot[0] = sm.red[0]; po.lj_pot[1] = sm.red[1];
+        po.lj_vir[0] = sm.red[2]; po.lj_vir[1] = sm.red[3];
+        po.qq_pot[0] = sm.red[4]; po.qq_pot[1] = sm.red[5];
+        po.recip = sm.red[6];
+        po.ovl[0] = of & 1; po.ovl[1] = (of >> 1) & 1;
+        out[(int64_t)r * n_parts + part] = po;
+    }
+}
+
+// settle for the record layout: as k_settle, plus rec.
+__global__ void k_settle_rec(BatchView bv, double *rec, const MoveRec *prev,
+                             const int32_t *accept, int r_base)
+{
+    const int r = r_base + blockIdx.x, t = threadIdx.x;
+    if (!accept[r] || t >= 12)
+        return;
+    const int m = prev[r].mol - 1;
+    const double v = (t < 9) ? prev[r].atoms_new[t] : prev[r].com_new[t - 9];
+    rec[((int64_t)r * bv.n_mol + m) * MMC_REC + t] = v;
+}

@@ -1,7 +1,7 @@
 // mmc_host.hpp -- host-side state shared by the context, batch and engine translation units.
 #pragma once
 #include "../../include/mmc_hip.h"
-#include "mmc_kernels.hpp"
+#include "mmc_fast.hpp"
 #include <string>
 #include <vector>
 
@@ -42,6 +42,11 @@ struct DeviceSystem {
     int64_t R = 0, n_mol = 0, n_atoms = 0, n_types = 0;
     double box = 0.0;
     bool uploaded = false, ewald_ready = false, uniform3 = false;
+    // fast path (mmc_fast.hpp): per-molecule records + erfc table; the batch asks for it
+    bool want_rec = false, homogeneous = false;
+    double *rec = nullptr;    // [R][n_mol][MMC_REC], only when want_rec && homogeneous
+    double *qq_tab = nullptr; // [MMC_QQ_NINT][MMC_QQ_NCOEF] for the prepared kappa
+    int32_t *kpack = nullptr; // [MMC_NK_STRIDE] packed k-vectors (k_pack_kvec)
     int64_t nk = 0, k_sq_max = 0, nkvecs = 0;
     BatchView bv{};
     std::vector<void *> allocs; // hipMalloc'ed

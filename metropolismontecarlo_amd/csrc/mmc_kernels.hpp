@@ -242,12 +242,17 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_move(BatchView bv, RecipMov
 }
 
 // ---- K1+K4 fused, batched: one trial move per replica ------------------------------------------
-// Layout-compatible with mmc_move (include/mmc_hip.h); `flags` reuses accept_prev:
-// bit 0 = commit this replica's previous proposal, bit 1 = which S buffer is current.
+// The device form of mmc_move (include/mmc_hip.h).  `flags`: bit 0 = commit this replica's
+// previous proposal, bit 1 = which S buffer is current.  com_old/atoms_old: the chosen molecule's
+// current state as the host mirror holds it (the values the device holds too) -- k_move_eval_fast
+// takes the old state from here so that nothing in it depends on a second memory round trip;
+// k_move_eval ignores them and reads the device arrays.
 struct MoveRec {
     int32_t mol, flags;
     double com_new[3];
     double atoms_new[9];
+    double com_old[3];
+    double atoms_old[9];
 };
 
 struct PartOut {

@@ -293,10 +293,19 @@ class Batch:
         a = np.ascontiguousarray(accept, dtype=np.int32)
         check(self._L.mmc_batch_settle(self._h, a.ctypes.data_as(_i32p)))
 
+    def set_option(self, key, value):
+        check(self._L.mmc_batch_set_option(self._h, key.encode(), int(value)))
+
+    def qq_table(self, r2):
+        r2 = _f64(r2).ravel()
+        out = np.empty_like(r2)
+        check(self._L.mmc_batch_qq_table(self._h, _d(r2), r2.shape[0], _d(out)))
+        return out
+
     def run(self, n_steps, temperature, dr_max, dphi_max, seed, energies=None, n_groups=2,
-            n_parts=0, time_kernels=False):
+            n_parts=0, time_kernels=False, n_threads=1):
         p = RunParams(float(temperature), float(dr_max), float(dphi_max), int(seed), int(n_steps),
-                      int(n_groups), int(n_parts), int(bool(time_kernels)), 0)
+                      int(n_groups), int(n_parts), int(bool(time_kernels)), int(n_threads))
         st = RunStats()
         e = np.zeros(self.R) if energies is None else _f64(energies).copy()
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))

@@ -1,0 +1,51 @@
+"""Multi-GPU layout of the replica ensemble: one process per GPU, replicas sharded by global
+index, no data-path collective.  The only collective (C1 in SURVEY.md) is the final reduction of a
+handful of observables -- sums of energies / acceptance counters and the max of the elapsed time --
+over RCCL (backend "nccl" on the GPU box, "gloo" in the CPU tests)."""
+import os
+
+import numpy as np
+
+BASE_SEED = 11234  # Monatomic/mainMonatomic.jl:15, the only seed the reference fixes
+
+OBSERVABLES = ("moves", "accepted", "overlaps", "energy_sum", "kernel_ms", "launches")
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def shard(replicas_per_gpu, rank):
+    """Weak scaling: every rank owns `replicas_per_gpu` chains; global index = rank*R + r."""
+    lo = rank * replicas_per_gpu
+    return range(lo, lo + replicas_per_gpu)
+
+
+def shard_total(total_replicas, rank, world):
+    """Strong scaling (BASELINE configs[2]: 256 replicas over 8 GPUs): contiguous blocks, the
+    first `total % world` ranks take one extra."""
+    base, extra = divmod(total_replicas, world)
+    lo = rank * base + min(rank, extra)
+    return range(lo, lo + base + (1 if rank < extra else 0))
+
+
+def replica_seed(global_index, phase=0):
+    """RNG stream of a chain depends on its GLOBAL index only, so a chain's trajectory does not
+    depend on how many GPUs the ensemble is spread over.  `phase` separates warm-up from the
+    timed run."""
+    return BASE_SEED + int(global_index) + 1_000_003 * int(phase)
+
+
+def reduce_observables(local, elapsed, dist=None, device="cpu"):
+    """SUM the observable vector and MAX the elapsed time over all ranks.  `dist` is
+    torch.distributed (initialised) or None for a single process."""
+    vec = np.array([float(local[k]) for k in OBSERVABLES], dtype=np.float64)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(zip(OBSERVABLES, vec)), float(elapsed)
+    import torch
+    t = torch.tensor(vec, dtype=torch.float64, device=device)
+    m = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    dist.all_reduce(m, op=dist.ReduceOp.MAX)
+    return dict(zip(OBSERVABLES, t.cpu().numpy())), float(m.item())

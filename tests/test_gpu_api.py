@@ -1,0 +1,151 @@
+"""GPU parity through the reference-named surface (metropolismontecarlo_amd/api.py): the body of
+Loop() (Ewald/main.jl:487-644) written with the reference's own calls and host-array mutations,
+compared with the oracle step by step."""
+import numpy as np
+import pytest
+
+import common
+from common import rel
+from metropolismontecarlo_amd import structs
+from metropolismontecarlo_amd.api import (CoulombReal, EwaldReal, EwaldSelf, EwaldShort,
+                                          LJ_poly_ΔU, PrepareEwaldVariables, RecipLong, RecipMove,
+                                          potential, release_sessions)
+from metropolismontecarlo_amd.structs import EWALD, Properties, Properties2, Requirements, Tables
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-9
+RCUT = 10.0
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(autouse=True)
+def _cleanup():
+    yield
+    release_sessions()
+
+
+def reference_setup(a):
+    """What Ewald/main.jl:242-303 builds: moa/soa, vdwTable, a dummy EWALD + PrepareEwaldVariables,
+    totProps."""
+    from metropolismontecarlo_amd import io as mio
+    moa = structs.make_moa(a["com"].copy(), a["first_atom"], a["last_atom"])
+    soa = structs.make_soa(a["coords"].copy(), a["atype"], a["charge"])
+    vdwTable = Tables([mio.SPCE_EPS_O, 0.0], [mio.SPCE_SIGMA_O, 0.0])
+    box = a["box"]
+    ewald = EWALD(5.6 / box, 5, 27, 1, [[1, 1, 1]] * 3, [0.0, 0.0], np.zeros(2, complex),
+                  np.zeros(2, complex), structs.factor)                  # main.jl:290-301
+    ewald = PrepareEwaldVariables(ewald, box)                            # main.jl:303
+    totProps = Properties2(298.15, 0.0331, 0.0, 0.3166, 0.05, 0.3, 0, 0, [], RCUT, RCUT, box)
+    return moa, soa, vdwTable, ewald, totProps, box
+
+
+@pytest.mark.parametrize("k,variant", [(1, "reference"), (4, "unwrapped")])
+def test_loop_body_with_reference_calls(k, variant, orc):
+    a = common.nist_arrays(k, variant)
+    g = common.golden(k, variant)
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    assert ewald.NKVECS == 337 and ewald.kxyz.shape == (337, 3)
+
+    total = potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")  # main.jl:408
+    assert rel(total.energy, g["totals_ewald"]["energy"]) < TOL
+    assert rel(total.virial, g["totals_ewald"]["virial"]) < TOL
+    assert rel(total.coulomb, g["totals_ewald"]["coulomb"]) < TOL
+    assert np.array_equal(ewald.sumQExpOld, ewald.sumQExpNew) and ewald.sumQExpOld.any()
+    running = total.energy
+
+    for mv in g["moves"]:
+        i = mv["mol"]
+        f, l = moa.firstAtom[i - 1], moa.lastAtom[i - 1]
+        partial_old_e, partial_old_v = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)   # :491
+        e, v, overlap1 = EwaldShort(i, moa, soa, totProps, ewald, box)               # :501
+        partial_old_v += v
+        partial_old_e += e
+        rm_old = moa.COM[i - 1].copy()                                               # :514
+        ra_old = soa.coords[f - 1:l].copy()                                          # :515
+        moa.COM[i - 1] = mv["com_new"]                                               # :527
+        soa.coords[f - 1:l] = mv["atoms_new"]                                        # :552
+        ra_new = soa.coords[f - 1:l].copy()
+        partial_new_e, partial_new_v = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)   # :557
+        e, v, overlap2 = EwaldShort(i, moa, soa, totProps, ewald, box)               # :566
+        partial_new_v += v
+        partial_new_e += e
+        overlap = overlap1 or overlap2
+        if not overlap:
+            deltaRecip, ewald = RecipMove(box, ewald, ra_old, ra_new, soa.charge[f - 1:l])  # :581
+        else:
+            deltaRecip = 0.0
+        delta = partial_new_e - partial_old_e + deltaRecip                           # :593
+        d_ref = mv["d"]
+        assert int(overlap) == mv["overlap"]
+        assert abs(delta - (d_ref[0] + d_ref[1] + d_ref[2])) < TOL * 1e5
+        assert abs((partial_new_v - partial_old_v) + deltaRecip / 3 - d_ref[3]) < TOL * 1e6
+        if mv["accept"]:
+            running += delta
+            ewald.sumQExpOld = [item for item in ewald.sumQExpNew]                   # :621
+            ewald.sumQExpOld = np.array(ewald.sumQExpOld)
+        else:
+            moa.COM[i - 1] = rm_old                                                  # :623
+            soa.coords[f - 1:l] = ra_old                                             # :624
+            ewald.sumQExpNew = np.array([item for item in ewald.sumQExpOld])         # :628
+        assert rel(np.abs(ewald.sumQExpOld).sum(), mv["sum_abs_S_old"]) < 1e-11
+
+    # Poly/main.jl:232-235 invariant through the reference surface
+    total2 = potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+    assert rel(running, total2.energy) < TOL
+    s = common.oracle_system(dict(a, com=moa.COM, coords=soa.coords))
+    to = orc.potential_ewald(s, orc.Ewald(5.6 / box, 5, 27, box), RCUT, RCUT)
+    assert rel(total2.energy, to["energy"]) < TOL
+
+
+def test_individual_reference_signatures(orc):
+    a = common.nist_arrays(2, "reference")
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    s = common.oracle_system(a)
+    ewo = orc.Ewald(5.6 / box, 5, 27, box)
+    # EwaldReal moa/soa form
+    e, ov = EwaldReal(7, moa, soa, ewald, RCUT, box)
+    eo, ovo = orc.ewald_real(7, s, ewo.kappa, RCUT)
+    assert ov == ovo and rel(e, eo) < TOL
+    # RecipLong(ewald, r, qq_q, box) -> (energy, ewald), fills both arrays
+    energy, ew2 = RecipLong(ewald, soa.coords, soa.charge, box)
+    assert ew2 is ewald and rel(energy, orc.recip_long(ewo, s.coords, s.charge, box)) < TOL
+    assert np.abs(ewald.sumQExpNew - ewo.sumQExpNew).max() < 1e-11 * np.abs(ewo.sumQExpNew).max()
+    assert rel(EwaldSelf(ewald, soa.charge), orc.ewald_self(ewo, s.charge)) < 1e-13
+    # Wolf total: the 6-argument potential (energy.jl:864-943)
+    w = potential(moa, soa, Properties(), ewald, vdwTable, totProps)
+    wo = orc.potential_wolf(s, ewo, RCUT, RCUT, literal_prefactor=False)
+    assert rel(w.energy, wo["energy"]) < TOL and rel(w.coulomb, wo["coulomb"]) < TOL
+    # legacy Requirements forms (energy.jl:126-206, ewalds.jl:205-289, energy.jl:618-711)
+    tma = np.stack([a["first_atom"], a["last_atom"]], axis=1)
+    system = Requirements(a["com"].copy(), a["coords"].copy(), len(a["com"]), len(a["coords"]),
+                          len(a["coords"]), tma, [], [], [], a["atype"], vdwTable, box, RCUT)
+    p, v = LJ_poly_ΔU(5, system)
+    po, vo = orc.lj_poly_du(5, s, RCUT)
+    assert rel(p, po) < TOL and rel(v, vo, abs(po)) < TOL
+    e, ov = EwaldReal(system.ra, a["charge"], ewald.kappa, box, tma, 5, system)
+    eo, ovo = orc.ewald_real(5, s, ewo.kappa, RCUT, ovr=1.0)
+    assert ov == ovo and rel(e, eo) < TOL
+    e, ov = CoulombReal(system.ra, a["charge"], box, 5, system)
+    eo, ovo = orc.coulomb_real(5, s, RCUT)
+    assert ov == ovo and rel(e, eo) < TOL
+    energy, _ = RecipLong(system, ewald, system.ra, a["charge"])
+    assert rel(energy, orc.recip_long(ewo, s.coords, s.charge, box)) < TOL
+
+
+def test_reference_asserts_surface_as_assertion_errors():
+    a = common.nist_arrays(1)
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    bad = EWALD(0.28, 5, 26, 1, [[1, 1, 1]], [0.0], [0j], [0j], structs.factor)
+    with pytest.raises(AssertionError):
+        PrepareEwaldVariables(bad, box)                       # ewalds.jl:49
+    with pytest.raises(AssertionError):
+        RecipMove(box, ewald, np.zeros((2, 3)), np.zeros((2, 3)), np.zeros(2))   # ewalds.jl:740
+    ew4 = PrepareEwaldVariables(EWALD(0.28, 4, 27, 1, [[1, 1, 1]], [0.0], [0j], [0j],
+                                      structs.factor), box)
+    with pytest.raises(AssertionError):
+        RecipMove(box, ew4, np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3))     # nk == 5, :743

@@ -50,10 +50,11 @@ def oracle_chain(orc, a, moves, accept_rule):
     return out, s, ew
 
 
+@pytest.mark.parametrize("kernel", [1, 0])
 @pytest.mark.parametrize("k,variant,parts", [(1, "reference", 1), (1, "reference", 4),
                                              (4, "reference", 0), (4, "unwrapped", 9),
-                                             (2, "unwrapped", 2)])
-def test_batch_eval_chain(k, variant, parts, orc):
+                                             (2, "unwrapped", 2), (3, "reference", 16)])
+def test_batch_eval_chain(k, variant, parts, kernel, orc):
     """Three replicas take the same proposals but different accept decisions, so their states
     diverge; every step's dU terms, overlap flags and the final device state (coordinates and
     S(k)) must match three independent oracle chains.  Proposals that touch the same molecule
@@ -72,6 +73,8 @@ def test_batch_eval_chain(k, variant, parts, orc):
     with make_batch(a, R) as b:
         if parts:
             b.set_parts(parts)
+        b.set_option("kernel", kernel)   # 1: LDS-tiled + erfc table (default), 0: generic
+        b.set_option("zero_copy_moves", k % 2)
         e0 = b.recip_long()
         ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
         assert rel(e0[0], orc.recip_long(ew, a["coords"], a["charge"], a["box"])) < TOL
@@ -106,9 +109,10 @@ def test_batch_parts_agree(orc):
     g = common.golden(4, "unwrapped")
     mv = g["moves"][0]
     ref = None
-    for parts in (1, 2, 3, 5, 9, 16):
+    for parts, kernel in ((1, 1), (2, 1), (3, 0), (5, 1), (9, 0), (16, 1), (1, 0)):
         with make_batch(a, 2) as b:
             b.set_parts(parts)
+            b.set_option("kernel", kernel)
             b.recip_long()
             d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (2, 1)),
                            np.tile(np.array(mv["atoms_new"]).ravel(), (2, 1)))
@@ -154,8 +158,33 @@ def test_batch_errors():
         make_batch(bad, 1)
 
 
-@pytest.mark.parametrize("R,groups,parts", [(1, 1, 0), (5, 2, 0), (16, 3, 1), (8, 2, 4)])
-def test_engine_running_total_vs_recompute(R, groups, parts, orc):
+def test_non_homogeneous_system_uses_generic_kernel(orc):
+    """Different charges on different molecules: the fast kernel does not apply, the batch must
+    fall back to the generic one by itself and refuse kernel=1."""
+    from metropolismontecarlo_amd._lib import MMCError
+    a = common.nist_arrays(1, "unwrapped")
+    a = dict(a, charge=a["charge"].copy())
+    a["charge"][3:6] *= 0.5          # molecule 2 is different (still neutral)
+    g = common.golden(1, "unwrapped")
+    mv = g["moves"][0]
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    do, ovo = orc.trial_move(mv["mol"], s, ew, RCUT, RCUT, np.array(mv["com_new"]),
+                             np.array(mv["atoms_new"]))
+    with make_batch(a, 2) as b:
+        with pytest.raises(MMCError, match="MMC_ERR_UNSUPPORTED"):
+            b.set_option("kernel", 1)
+        b.recip_long()
+        d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (2, 1)),
+                       np.tile(np.array(mv["atoms_new"]).ravel(), (2, 1)))
+        assert ov[0] == ovo and np.abs(d[0] - do).max() < TOL * (np.abs(do).max() + 1e4)
+
+
+@pytest.mark.parametrize("R,groups,parts,threads,kernel",
+                         [(1, 1, 0, 1, 1), (5, 2, 0, 1, 1), (16, 3, 1, 3, 1), (8, 2, 4, 2, 0),
+                          (12, 4, 0, 2, 1)])
+def test_engine_running_total_vs_recompute(R, groups, parts, threads, kernel, orc):
     """The reference's only integration invariant (Poly/main.jl:232-235): the running total
     energy (initial + accepted deltas) equals a full recompute -- here after hundreds of native
     driver steps, which also proves that commits reached the device coordinates and that the
@@ -163,10 +192,11 @@ def test_engine_running_total_vs_recompute(R, groups, parts, orc):
     a = common.nist_arrays(1, "unwrapped")
     n_steps = 260  # > 2 sweeps of 100 molecules: every molecule is proposed several times
     with make_batch(a, R) as b:
+        b.set_option("kernel", kernel)
         t0 = b.potential_ewald()
         e0 = np.array([t["energy"] for t in t0])
         e1, st = b.run(n_steps, 298.15, 0.316555789, 0.05, seed=11234, energies=e0,
-                       n_groups=groups, n_parts=parts)
+                       n_groups=groups, n_parts=parts, n_threads=threads)
         assert st["moves"] == n_steps * R
         assert st["trans_attempt"] + st["rot_attempt"] == n_steps * R
         acc = st["trans_accept"] + st["rot_accept"]
@@ -189,10 +219,11 @@ def test_engine_running_total_vs_recompute(R, groups, parts, orc):
 def test_engine_deterministic_and_group_independent():
     a = common.nist_arrays(1, "unwrapped")
     res = []
-    for groups, parts in ((1, 1), (3, 1), (2, 5)):
+    for groups, parts, threads in ((1, 1, 1), (3, 1, 3), (2, 5, 2)):
         with make_batch(a, 6) as b:
             b.recip_long()
-            e, st = b.run(150, 298.15, 0.316555789, 0.05, seed=7, n_groups=groups, n_parts=parts)
+            e, st = b.run(150, 298.15, 0.316555789, 0.05, seed=7, n_groups=groups, n_parts=parts,
+                          n_threads=threads)
             res.append((e, st))
     # same workgroup split -> bitwise identical whatever the stream grouping
     assert np.array_equal(res[0][0], res[1][0])
