@@ -88,10 +88,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--replicas", type=int, default=1024, help="replicas per GPU")
-    ap.add_argument("--groups", type=int, default=4, help="replica groups pipelined per GPU")
+    ap.add_argument("--replicas", type=int, default=16384, help="replicas per GPU")
+    ap.add_argument("--groups", type=int, default=2, help="replica groups pipelined per GPU")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
-    ap.add_argument("--threads", type=int, default=4, help="host threads driving the groups")
+    ap.add_argument("--threads", type=int, default=8, help="host threads per GPU for the accept/reject")
     ap.add_argument("--kernel", type=int, default=1, help="1 = LDS-tiled kernel, 0 = generic")
     ap.add_argument("--zero-copy-moves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

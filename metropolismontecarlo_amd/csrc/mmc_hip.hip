@@ -6,3 +6,4 @@
 #include "mmc_system.inc"
 #include "mmc_ctx.inc"
 #include "mmc_batch.inc"
+#include "mmc_engine.inc"
