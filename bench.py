@@ -55,6 +55,22 @@ def algorithmic_bytes_full_eval(n_mol, n_k=N_K):
     return 36 * 3 * n_mol + 24 * n_mol + 36 * n_k
 
 
+def pmc_traffic(args, moves_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 on gfx950; profiles/*_traffic.json).
+    PMC counters cannot be collected from inside this process, so the number is reported only when
+    this run has the launch shape the counters were collected for; otherwise null."""
+    try:
+        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
+                      if p.endswith("_traffic.json"))[-1]
+        t = json.load(open(os.path.join(ROOT, "profiles", path)))
+    except (IndexError, OSError, ValueError):
+        return None
+    if args.kernel != 1 or int(moves_per_launch) != int(t["moves_per_launch"]):
+        return None
+    return t["bytes_per_launch"]
+
+
 def cpu_baseline(a, budget_s):
     """Time the oracle (C port, 1 thread) on the same workload: Loop()'s hot-path calls for
     successive molecules with small rigid translations, for about `budget_s` seconds."""
@@ -205,9 +221,10 @@ def main():
             t_launch = st["kernel_ms"] * 1e-3 / launches  # rank 0's average launch duration
             achieved = bytes_move * replicas_per_launch / t_launch / 1e9
             out["roofline"] = {
-                "kernel": "k_move_eval", "bound": "hbm", "achieved": achieved,
+                "kernel": "k_move_eval_fast" if args.kernel == 1 else "k_move_eval",
+                "bound": "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args, replicas_per_launch),
                 "avg_launch_us": 1e6 * t_launch, "launches": int(launches),
                 "algorithmic_bytes_per_move": bytes_move,
                 "moves_per_launch": replicas_per_launch,

@@ -38,7 +38,8 @@ mutable struct Session
     box::Float64
     last_mol::Int64
     ewald_key::Tuple
-    s_ids::Tuple{UInt,UInt}
+    s_old::Vector{ComplexF64}   # host copies of what the device S buffers hold
+    s_new::Vector{ComplexF64}
 end
 
 const SESSION = Ref{Union{Nothing,Session}}(nothing)
@@ -66,7 +67,7 @@ function attach!(moa, soa, vdwTable, box::Float64; device::Integer = 0)
                     pointer(coords), pointer(atype), pointer(charge), size(eps, 1), pointer(eps),
                     pointer(sig), box))
     end
-    SESSION[] = Session(ctx[], box, 0, (), (UInt(0), UInt(0)))
+    SESSION[] = Session(ctx[], box, 0, (), ComplexF64[], ComplexF64[])
     return SESSION[]
 end
 
@@ -112,7 +113,7 @@ function bind_ewald!(s::Session, ewald, box)
                     (Ptr{Cvoid}, Float64, Int64, Int64, Float64, Float64, Ptr{Int64}),
                     s.ctx, ewald.kappa, ewald.nk, ewald.k_sq_max, box, ewald.factor, n))
         s.ewald_key = key
-        s.s_ids = (UInt(0), UInt(0))
+        s.s_old = ComplexF64[]; s.s_new = ComplexF64[]   # device arrays were zeroed
     end
 end
 
@@ -120,13 +121,13 @@ end
 # arrays are not the ones the device mirrors.
 function push_s!(s::Session, ewald)
     so, sn = ewald.sumQExpOld, ewald.sumQExpNew
-    ids = (UInt(pointer(so)), UInt(pointer(sn)))
-    if ids != s.s_ids
+    # compare CONTENT (337 complex numbers): array identity can be recycled by the allocator
+    if so != s.s_old || sn != s.s_new
         GC.@preserve so sn begin
             check(ccall((:mmc_set_sumqexp, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                         s.ctx, pointer(so), pointer(sn)))
         end
-        s.s_ids = ids
+        s.s_old = copy(so); s.s_new = copy(sn)
     end
 end
 
@@ -136,7 +137,10 @@ function pull_s!(s::Session, ewald; old::Bool = false)
         check(ccall((:mmc_get_sumqexp, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
                     s.ctx, old ? pointer(so) : C_NULL, pointer(sn)))
     end
-    s.s_ids = (UInt(pointer(so)), UInt(pointer(sn)))
+    if old
+        s.s_old = copy(so)
+    end
+    s.s_new = copy(sn)
 end
 
 # ---- the reference's methods -------------------------------------------------------------------
