@@ -112,6 +112,8 @@ def main():
     ap.add_argument("--zero-copy-moves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the 1-replica and 32-replica side measurements")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket launches with HIP events in the timed region")
     args = ap.parse_args()
@@ -230,6 +232,24 @@ def main():
                 "moves_per_launch": replicas_per_launch,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             }
+        if not args.no_secondary:
+            # the same path at BASELINE's two named replica counts, on this rank's GPU:
+            # configs[1] = one chain (latency-bound), configs[2] = 256 replicas over 8 GPUs = 32/GPU
+            out["other_configs"] = {}
+            for name, r2, g2, t2 in (("configs[1]: 1 replica on 1 GPU", 1, 1, 1),
+                                     ("configs[2] share: 32 replicas per GPU", 32, 2, 2)):
+                b2 = Batch(r2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"],
+                           box, 5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
+                e2 = np.array([t["energy"] for t in b2.potential_ewald()])
+                e2, _ = b2.run(200, TEMPERATURE, DR_MAX, DPHI_MAX, SEED, e2, n_groups=g2,
+                               n_threads=t2)
+                t0 = time.perf_counter()
+                e2, s2 = b2.run(2000, TEMPERATURE, DR_MAX, DPHI_MAX, SEED + 1, e2, n_groups=g2,
+                                n_threads=t2)
+                dt2 = time.perf_counter() - t0
+                b2.close()
+                out["other_configs"][name] = {"moves_per_s_per_gpu": s2["moves"] / dt2,
+                                              "us_per_step": 1e6 * dt2 / 2000}
         if not args.no_cpu:
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {

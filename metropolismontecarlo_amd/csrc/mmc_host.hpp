@@ -1,7 +1,7 @@
 // mmc_host.hpp -- host-side state shared by the context, batch and engine translation units.
 #pragma once
 #include "../../include/mmc_hip.h"
-#include "mmc_fast.hpp"
+#include "mmc_total.hpp"
 #include <string>
 #include <vector>
 
@@ -42,11 +42,18 @@ struct DeviceSystem {
     int64_t R = 0, n_mol = 0, n_atoms = 0, n_types = 0;
     double box = 0.0;
     bool uploaded = false, ewald_ready = false, uniform3 = false;
-    // fast path (mmc_fast.hpp): per-molecule records + erfc table; the batch asks for it
-    bool want_rec = false, homogeneous = false;
-    double *rec = nullptr;    // [R][n_mol][MMC_REC], only when want_rec && homogeneous
+    // fast paths (mmc_fast.hpp, mmc_total.hpp): systems whose molecules are all copies of one
+    // 3-atom molecule get per-molecule records, launch constants and the erfc table
+    bool homogeneous = false;
+    double *rec = nullptr;    // [R][n_mol][MMC_REC], only when homogeneous
+    FastConsts fc{};          // launch constants of the fast kernels
     double *qq_tab = nullptr; // [MMC_QQ_NINT][MMC_QQ_NCOEF] for the prepared kappa
     int32_t *kpack = nullptr; // [MMC_NK_STRIDE] packed k-vectors (k_pack_kvec)
+    int16_t *tile_pairs = nullptr; // [n_tile_pairs][2], I <= J (k_total_pairs)
+    int n_tile_pairs = 0;
+    TotalPart *d_tparts = nullptr; // [R][n_tile_pairs], lazily
+    double *d_phase = nullptr;     // [R][n_atoms][6], lazily (k_atom_phases)
+    bool fast_table_ok(double qq_rcut) const; // the erfc table covers this cutoff
     int64_t nk = 0, k_sq_max = 0, nkvecs = 0;
     BatchView bv{};
     std::vector<void *> allocs; // hipMalloc'ed
@@ -54,6 +61,7 @@ struct DeviceSystem {
     std::vector<double> h_charge;
     // scratch
     MolE *d_permol = nullptr;      // [R][n_mol]
+    void *d_scr = nullptr;         // 64 B per replica: reduced results before the D2H copy
     void *h_res = nullptr;         // pinned, mapped: small per-call results (4 KiB)
     void *d_res = nullptr;         // device alias of h_res
     double *d_stage = nullptr;     // device staging for AoS uploads/downloads (3*n_atoms)
@@ -77,6 +85,8 @@ struct DeviceSystem {
                        MolE *out, int out_stride);
     int32_t recip_long_all(double *energies_host /* [R] */);
     int32_t totals_ewald(double lj_rcut, double qq_rcut, mmc_totals *tot /* [R] */);
+    // sum_i 4 pot_i, sum_i 8 vir_i, sum_i EwaldReal_i and the overlap count, per replica
+    int32_t pair_totals(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht);
     int32_t charge_sums(double *sum_q, double *sum_q2);
 };
 

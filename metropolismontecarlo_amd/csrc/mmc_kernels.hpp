@@ -264,9 +264,11 @@ struct PartOut {
 // grid (n_parts, R).  n_parts == 1: the workgroup scans all molecules and then does the
 // reciprocal part.  n_parts > 1: parts 0..n_parts-2 split the molecule range, the last part does
 // the reciprocal part -- this is how a small replica count still fills 256 CUs.
+// `rec`: the record array of homogeneous systems (kept in step by the commit) or NULL.
 __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const MoveRec *cur,
                                                          const MoveRec *prev, PartOut *out,
-                                                         int n_parts, PairParams pp, int r_base)
+                                                         int n_parts, PairParams pp, int r_base,
+                                                         double *rec)
 {
     __shared__ Chosen ch;
     __shared__ Pending pd;
@@ -324,6 +326,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
             w = (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az) + r * bv.atom_stride + fa + a;
             *w = prev[r].atoms_new[tid - 3];
         }
+        if (rec) // [atoms(9), com(3)] record of the molecule (mmc_fast.hpp)
+            rec[((int64_t)r * bv.n_mol + pend) * 12 + (tid < 3 ? 9 + tid : tid - 3)] = *w;
     }
     __syncthreads();
 
@@ -391,7 +395,8 @@ struct SetMolArgs {
     double at[MMC_MAX_ATOMS][3];
 };
 
-__global__ void k_set_molecule(BatchView bv, SetMolArgs a)
+// rec: the 12-double record array of homogeneous systems (mmc_fast.hpp) or NULL.
+__global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
 {
     const int t = threadIdx.x;
     if (t < 3)
@@ -399,6 +404,10 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a)
     if (t < a.na) {
         const int64_t o = a.r * bv.atom_stride + bv.first0[a.i0] + t;
         bv.ax[o] = a.at[t][0]; bv.ay[o] = a.at[t][1]; bv.az[o] = a.at[t][2];
+    }
+    if (rec && t < 12) {
+        double *o = rec + ((int64_t)a.r * bv.n_mol + a.i0) * 12;
+        o[t] = t < 9 ? a.at[t / 3][t % 3] : a.com[t - 9];
     }
 }
 

@@ -1,0 +1,273 @@
+// mmc_total.hpp -- K2/K3 for homogeneous 3-atom systems: the total energy
+// `potential(moa, soa, tot, ewalds, vdwTable, sim_props, "ewald")` (Ewald/energy.jl:946-1032)
+// with each molecule pair visited ONCE.
+//
+// The reference sums LJ_poly_dU(i) and EwaldReal(i) over all i and halves (energy.jl:972-1001):
+// every pair twice.  Pair terms and the COM gate are symmetric in (i, j), so
+//     sum_i E_i / 2 = sum_{i<j} e_ij
+// holds term by term; only the summation order changes (~1e-15 relative).  The one asymmetric
+// piece is the overlap sentinel (EwaldReal returns 0.0 for a molecule that overlaps,
+// ewalds.jl:359-360): the kernel counts overlapping atom pairs and the host falls back to the
+// per-molecule kernels for a replica that has any, so the quirk is reproduced exactly.
+//
+//   k_total_pairs   grid (tile pairs I<=J, R): two 64-molecule record tiles in LDS, COM gate of
+//                   the 64x64 molecule pairs -> compacted list -> one lane per (pair, a, b) with
+//                   the erfc(kappa r)/r table of mmc_fast.hpp; LJ pass for eps > 0.001 pairs.
+//   k_total_sum     per-replica sum of the tile-pair partials, fixed order.
+//   k_atom_phases   cos/sin(2 pi x/L) for every atom once (6 doubles), instead of once per
+//                   (kx, ky) column as k_recip_long does.
+//   k_recip_long_ph k_recip_long reading those phases.
+#pragma once
+#include "mmc_fast.hpp"
+
+#define MMC_TM 64 // molecules per tile
+
+struct TotalPart {
+    double lj_pot, lj_vir, qq;
+    int32_t n_ovl, _pad;
+};
+
+struct TotalShared {
+    alignas(16) double ti[MMC_TM * MMC_REC]; // 6 KB each; ti doubles as reduction scratch
+    alignas(16) double tj[MMC_TM * MMC_REC];
+    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    double red[4];
+    double qq9[9], ljp_eps[9], ljp_sig[9];
+    uint16_t list[MMC_TM * MMC_TM];
+    int32_t ljp_ab[9];
+    int32_t wcnt[MMC_WAVES];
+};
+static_assert(2 * MMC_TM * MMC_REC >= 4 * MMC_BLOCK, "tiles double as reduction scratch");
+
+__global__ __launch_bounds__(MMC_BLOCK) void k_total_pairs(BatchView bv, const double *rec,
+                                                           const double *qq_tab, FastConsts fc,
+                                                           PairParams pp, const int16_t *tile_pairs,
+                                                           int n_pairs, TotalPart *out)
+{
+    __shared__ __align__(16) TotalShared sm;
+    const int r = blockIdx.y, tp = blockIdx.x, tid = threadIdx.x;
+    const int n_mol = bv.n_mol;
+    const double box = bv.box;
+    const int ti_idx = tile_pairs[2 * tp], tj_idx = tile_pairs[2 * tp + 1];
+    const bool diag = ti_idx == tj_idx;
+    const int i0 = ti_idx * MMC_TM, j0 = tj_idx * MMC_TM;
+    const int ni = min(MMC_TM, n_mol - i0), nj = min(MMC_TM, n_mol - j0);
+    const double *myrec = rec + (int64_t)r * n_mol * MMC_REC;
+
+    // tiles are contiguous runs of records: straight 16-byte copies
+    for (int g = tid; g < ni * 6; g += MMC_BLOCK)
+        *reinterpret_cast<double2 *>(&sm.ti[2 * g]) =
+            *reinterpret_cast<const double2 *>(myrec + (int64_t)i0 * MMC_REC + 2 * g);
+    for (int g = tid; g < nj * 6; g += MMC_BLOCK)
+        *reinterpret_cast<double2 *>(&sm.tj[2 * g]) =
+            *reinterpret_cast<const double2 *>(myrec + (int64_t)j0 * MMC_REC + 2 * g);
+    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += MMC_BLOCK)
+        sm.qtab[k] = qq_tab[k];
+    if (tid < 9) {
+        sm.qq9[tid] = fc.qq9[tid];
+        sm.ljp_eps[tid] = fc.ljp_eps[tid];
+        sm.ljp_sig[tid] = fc.ljp_sig[tid];
+        sm.ljp_ab[tid] = fc.ljp_ab[tid];
+    }
+    __syncthreads();
+
+    // ---- COM gate of the tile's molecule pairs (energy.jl:248-254, ewalds.jl:334-340) ----
+    const int w = wave_id();
+    const int per_wave = MMC_TM * MMC_TM / MMC_WAVES; // 1024 pairs, 16 rows of 64
+    int count = 0;
+    for (int it = 0; it < per_wave / 64; it++) {
+        const int p = w * per_wave + it * 64 + lane_id();
+        const int ii = p >> 6, jj = p & 63; // ii is wave-uniform: its COM is an LDS broadcast
+        int f = 0;
+        if (ii < ni && jj < nj && (!diag || ii < jj)) {
+            const double dx = vector1D(sm.ti[ii * MMC_REC + 9], sm.tj[jj * MMC_REC + 9], box);
+            const double dy = vector1D(sm.ti[ii * MMC_REC + 10], sm.tj[jj * MMC_REC + 10], box);
+            const double dz = vector1D(sm.ti[ii * MMC_REC + 11], sm.tj[jj * MMC_REC + 11], box);
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            f = ((r2 < pp.lj_gate_sq) ? 1 : 0) | ((r2 < pp.qq_gate_sq) ? 2 : 0);
+        }
+        const unsigned long long m = __ballot(f != 0);
+        if (f)
+            sm.list[w * per_wave + count + lanes_below(m)] = (uint16_t)(p | (f << 12));
+        count += __popcll(m);
+    }
+    if (lane_id() == 0)
+        sm.wcnt[w] = count;
+    __syncthreads();
+    const int c0 = sm.wcnt[0], c1 = sm.wcnt[1], c2 = sm.wcnt[2], c3 = sm.wcnt[3];
+    const int total = c0 + c1 + c2 + c3;
+    auto entry = [&](int pos) {
+        int slot;
+        if (pos < c0) slot = pos;
+        else if (pos < c0 + c1) slot = per_wave + (pos - c0);
+        else if (pos < c0 + c1 + c2) slot = 2 * per_wave + (pos - c0 - c1);
+        else slot = 3 * per_wave + (pos - c0 - c1 - c2);
+        return (int)sm.list[slot];
+    };
+
+    double a_lj = 0.0, a_v = 0.0, a_q = 0.0;
+    int n_ovl = 0;
+    // ---- Coulomb pass: one lane per (molecule pair, a, b) (ewalds.jl:343-372) ----
+    for (int g = tid; g < total * 9; g += MMC_BLOCK) {
+        const int n = g / 9, ab = g - n * 9;
+        const int a = ab / 3, b = ab - 3 * a;
+        const int e = entry(n);
+        if (e & (2 << 12)) {
+            const int ii = (e >> 6) & 63, jj = e & 63;
+            const double *pa = &sm.ti[ii * MMC_REC + 3 * a], *pb = &sm.tj[jj * MMC_REC + 3 * b];
+            const double rx = vector1D(pa[0], pb[0], box);
+            const double ry = vector1D(pa[1], pb[1], box);
+            const double rz = vector1D(pa[2], pb[2], box);
+            const double rab2 = rx * rx + ry * ry + rz * rz;
+            const double qq = sm.qq9[ab];
+            if ((rab2 < pp.ovr) && (qq < 0))
+                n_ovl = 1;
+            else if (rab2 < pp.qq_slack_sq)
+                a_q += qq * qq_pair(sm.qtab, rab2, pp.kappa);
+        }
+    }
+    // ---- LJ pass: atom pairs with eps > 0.001 (energy.jl:257-285) ----
+    const int n_ljp = fc.n_ljp;
+    for (int g = tid; g < total * n_ljp; g += MMC_BLOCK) {
+        int n = g, p = 0;
+        if (n_ljp != 1) {
+            n = g / n_ljp;
+            p = g - n * n_ljp;
+        }
+        const int e = entry(n);
+        if (e & (1 << 12)) {
+            const int ii = (e >> 6) & 63, jj = e & 63;
+            const int ab = sm.ljp_ab[p];
+            const int a = ab / 3, b = ab - 3 * a;
+            const double *ri = &sm.ti[ii * MMC_REC], *rj = &sm.tj[jj * MMC_REC];
+            const double rx = vector1D(ri[3 * a], rj[3 * b], box);
+            const double ry = vector1D(ri[3 * a + 1], rj[3 * b + 1], box);
+            const double rz = vector1D(ri[3 * a + 2], rj[3 * b + 2], box);
+            const double rab2 = rx * rx + ry * ry + rz * rz;
+            if (rab2 < pp.lj_slack_sq) {
+                const double eps = sm.ljp_eps[p], sg = sm.ljp_sig[p];
+                const double cx = vector1D(ri[9], rj[9], box);
+                const double cy = vector1D(ri[10], rj[10], box);
+                const double cz = vector1D(ri[11], rj[11], box);
+                const double s2 = sg * sg / rab2;
+                const double s6 = s2 * s2 * s2;
+                const double s12 = s6 * s6;
+                const double virab = eps * (2.0 * s12 - s6);
+                const double f0 = rx * virab * s2, f1 = ry * virab * s2, f2 = rz * virab * s2;
+                a_lj += eps * (s12 - s6);
+                a_v += cx * f0 + cy * f1 + cz * f2;
+            }
+        }
+    }
+    __syncthreads(); // tiles are read no more: reuse them as reduction scratch
+    double v[3] = { a_lj, a_v, a_q };
+    block_sum_wide<3>(v, sm.ti, sm.red, n_ovl, sm.wcnt);
+    if (tid == 0) {
+        TotalPart o;
+        o.lj_pot = sm.red[0]; o.lj_vir = sm.red[1]; o.qq = sm.red[2];
+        o.n_ovl = sm.wcnt[0] | sm.wcnt[1] | sm.wcnt[2] | sm.wcnt[3];
+        o._pad = 0;
+        out[(int64_t)r * n_pairs + tp] = o;
+    }
+}
+
+// per replica: sum the tile-pair partials in index order.  out: TotalsRaw in the reference's
+// normalisation (sum_i 4 pot_i etc., which the host halves): pairs counted once -> x2.
+__global__ void k_total_sum(const TotalPart *parts, int n_pairs, int n_rep, TotalsRaw *out)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rep)
+        return;
+    double lj = 0.0, vir = 0.0, qq = 0.0;
+    int ov = 0;
+    const TotalPart *p = parts + (int64_t)r * n_pairs;
+    for (int k = 0; k < n_pairs; k++) {
+        lj += p[k].lj_pot; vir += p[k].lj_vir; qq += p[k].qq; ov |= p[k].n_ovl;
+    }
+    TotalsRaw t;
+    t.lj_e = 2.0 * (lj * 4);          // energy.jl:289, both directions
+    t.lj_v = 2.0 * (vir * 24 / 3.0);
+    t.qq = 2.0 * qq;
+    t.n_ovl = ov; t._pad = 0;
+    out[r] = t;
+}
+
+// cos/sin of 2 pi c / L for the three coordinates of every atom (ewalds.jl:564-569), once.
+// ph[r][l][0..5] = cos x, sin x, cos y, sin y, cos z, sin z
+__global__ void k_atom_phases(BatchView bv, double *ph)
+{
+    const int l = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (l >= bv.n_atoms)
+        return;
+    const double L = bv.box;
+    const int64_t a = r * bv.atom_stride + l;
+    double *o = ph + ((int64_t)r * bv.n_atoms + l) * 6;
+    double sn, cs;
+    sincos(MMC_TWOPI * bv.ax[a] / L, &sn, &cs); o[0] = cs; o[1] = sn;
+    sincos(MMC_TWOPI * bv.ay[a] / L, &sn, &cs); o[2] = cs; o[3] = sn;
+    sincos(MMC_TWOPI * bv.az[a] / L, &sn, &cs); o[4] = cs; o[5] = sn;
+}
+
+// k_recip_long with the phases read instead of recomputed per (kx, ky) column.
+__global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const double *ph)
+{
+    __shared__ double red[2 * MMC_NKTAB * MMC_WAVES];
+    const int r = blockIdx.y;
+    const int kx = blockIdx.x / MMC_NKTAB, ky = blockIdx.x % MMC_NKTAB - 5;
+    const int aky = ky < 0 ? -ky : ky;
+    const double *myph = ph + (int64_t)r * bv.n_atoms * 6;
+    double acc[2 * MMC_NKTAB];
+#pragma unroll
+    for (int k = 0; k < 2 * MMC_NKTAB; k++)
+        acc[k] = 0.0;
+    for (int l = threadIdx.x; l < bv.n_atoms; l += MMC_BLOCK) {
+        const double q = bv.charge[l];
+        const double2 px = *reinterpret_cast<const double2 *>(myph + 6 * l),
+                      py = *reinterpret_cast<const double2 *>(myph + 6 * l + 2),
+                      pz = *reinterpret_cast<const double2 *>(myph + 6 * l + 4);
+        const cplx x1 = { px.x, px.y }, y1 = { py.x, py.y }, z1 = { pz.x, pz.y };
+        cplx ex = { 1.0, 0.0 }, ey = { 1.0, 0.0 };
+        if (kx > 0) {
+            ex = x1;
+            for (int k = 2; k <= kx; k++)
+                ex = c_mul(ex, x1);
+        }
+        if (aky > 0) {
+            ey = y1;
+            for (int k = 2; k <= aky; k++)
+                ey = c_mul(ey, y1);
+            if (ky < 0)
+                ey = c_conj(ey);
+        }
+        cplx ez[MMC_NKTAB];
+        const cplx one = { 1.0, 0.0 };
+        ez[5] = one; ez[6] = z1; ez[4] = c_conj(z1);
+        cplx p = z1;
+#pragma unroll
+        for (int k = 2; k <= 5; k++) {
+            p = c_mul(p, z1);
+            ez[5 + k] = p;
+            ez[5 - k] = c_conj(p);
+        }
+        const cplx qxy = c_mul(c_rmul(q, ex), ey);
+#pragma unroll
+        for (int k = 0; k < MMC_NKTAB; k++) {
+            const cplx t = c_mul(qxy, ez[k]);
+            acc[2 * k] += t.re;
+            acc[2 * k + 1] += t.im;
+        }
+    }
+    double tot[2 * MMC_NKTAB];
+    block_sum<2 * MMC_NKTAB>(acc, red, tot);
+    if (threadIdx.x == 0) {
+        double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
+#pragma unroll
+        for (int k = 0; k < MMC_NKTAB; k++) {
+            const int idx = bv.kmap[(kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB + k];
+            if (idx >= 0) {
+                s0[2 * idx] = tot[2 * k]; s0[2 * idx + 1] = tot[2 * k + 1];
+                s1[2 * idx] = tot[2 * k]; s1[2 * idx + 1] = tot[2 * k + 1];
+            }
+        }
+    }
+}
