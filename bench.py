@@ -250,6 +250,28 @@ def main():
                 b2.close()
                 out["other_configs"][name] = {"moves_per_s_per_gpu": s2["moves"] / dt2,
                                               "us_per_step": 1e6 * dt2 / 2000}
+            # configs[3]: 10 000 SPC/E, NPT volume move = K6 (new kappa, k-vectors, erfc table) +
+            # K2 (all molecule pairs) + K3 (structure factor), volume perturbed by +-0.5 %
+            from metropolismontecarlo_amd import io as mio
+            from metropolismontecarlo_amd.device import Context
+            nm4 = 10000
+            box4, com4, coords4 = mio.cubic_lattice_water(nm4, 0.033101144, "spce", seed=SEED)
+            first4 = 3 * np.arange(nm4, dtype=np.int64) + 1
+            ctx = Context(local_rank)
+            ctx.upload_system(com4, first4, first4 + 2, coords4, np.tile([1, 2, 2], nm4),
+                              np.tile([mio.SPCE_Q_O, mio.SPCE_Q_H, mio.SPCE_Q_H], nm4), a["eps"],
+                              a["sig"], box4)
+            ctx.prepare_ewald(5.6 / box4, 5, 27, box4, structs.factor)
+            ctx.potential_ewald(RCUT, RCUT)
+            n_vol, t0 = 20, time.perf_counter()
+            for i in range(n_vol):
+                L4 = (box4 ** 3 * (1.005 if i % 2 == 0 else 1.0)) ** (1.0 / 3.0)
+                ctx.volume_change(L4, 5.6 / L4)
+                e4 = ctx.potential_ewald(RCUT, RCUT)["energy"]
+            dt4 = time.perf_counter() - t0
+            ctx.close()
+            out["other_configs"]["configs[3]: 10 000 SPC/E, NPT volume move (K6+K2+K3)"] = {
+                "ms_per_volume_move": 1e3 * dt4 / n_vol, "energy_K": e4}
         if not args.no_cpu:
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {

@@ -82,6 +82,13 @@ int32_t mmc_set_molecule(mmc_ctx *ctx, int64_t i, const double *com, const doubl
  * NULL to re-send the atoms only (all that RecipLong reads). */
 int32_t mmc_update_system(mmc_ctx *ctx, const double *com, const double *coords);
 int32_t mmc_download_system(mmc_ctx *ctx, double *com, double *coords);
+/* The device part of an NPT volume move.  The reference only specifies it in prose
+ * (Ewald/volumeChange.jl:59-80): centres of mass scale by new_box/box, atoms translate rigidly
+ * with their molecule; then everything that depends on the box is rebuilt -- kappa (alpha/L,
+ * Ewald/main.jl:290-291), kxyz/cfac (PrepareEwaldVariables, Ewald/ewalds.jl:45-103), zeroed
+ * sumQExp arrays.  Follow with mmc_potential_ewald for the energy at the new volume
+ * (volumeChange.jl:91-111). */
+int32_t mmc_volume_change(mmc_ctx *ctx, double new_box, double new_kappa);
 
 /* PrepareEwaldVariables(ewald, boxSize)                       Ewald/ewalds.jl:45-103
  * Builds kxyz/cfac on the device, zeroes sumQExpOld/New.  k_sq_max != 27 -> MMC_ERR_ASSERT (:49).
@@ -186,6 +193,8 @@ int32_t mmc_batch_get_replica(mmc_batch *b, int64_t r, double *com, double *coor
 int32_t mmc_batch_recip_long(mmc_batch *b, double *energies);
 /* potential(..., "ewald") for every replica. */
 int32_t mmc_batch_potential_ewald(mmc_batch *b, mmc_totals *tot);
+/* mmc_volume_change for every replica of the batch (they share one box). */
+int32_t mmc_batch_volume_change(mmc_batch *b, double new_box, double new_kappa);
 /* One trial move per replica, one launch: moves[r] -> results[r].  moves[r].accept_prev settles
  * the replica's previous proposal first.  Synchronous. */
 int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *results);

@@ -79,6 +79,8 @@ SIGNATURES = {
     "mmc_set_molecule": [_vp, _i64, _dp, _dp],
     "mmc_update_system": [_vp, _dp, _dp],
     "mmc_download_system": [_vp, _dp, _dp],
+    "mmc_volume_change": [_vp, _d, _d],
+    "mmc_batch_volume_change": [_vp, _d, _d],
     "mmc_prepare_ewald": [_vp, _d, _i64, _i64, _d, _d, _i64p],
     "mmc_get_kvectors": [_vp, _i32p, _dp],
     "mmc_get_sumqexp": [_vp, _dp, _dp],

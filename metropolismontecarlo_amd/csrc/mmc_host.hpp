@@ -88,6 +88,8 @@ struct DeviceSystem {
     // sum_i 4 pot_i, sum_i 8 vir_i, sum_i EwaldReal_i and the overlap count, per replica
     int32_t pair_totals(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht);
     int32_t charge_sums(double *sum_q, double *sum_q2);
+    // volume move: rescale every replica to `new_box` and rebuild the Ewald tables (K6)
+    int32_t volume_change(double new_box, double new_kappa);
 };
 
 PairParams mmc_pair_params(double lj_rcut, double qq_rcut, double diameter, double ovr,

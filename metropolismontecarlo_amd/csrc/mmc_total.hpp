@@ -192,6 +192,39 @@ __global__ void k_total_sum(const TotalPart *parts, int n_pairs, int n_rep, Tota
     out[r] = t;
 }
 
+// Volume move, coordinate part (volumeChange.jl:62-80, the reference's NPT specification): centres
+// of mass scale by f = L_new / L_old, atoms translate rigidly with their molecule.
+// grid (ceil(n_mol/256), R).
+__global__ void k_rescale(BatchView bv, double *rec, double f)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+    if (j >= bv.n_mol)
+        return;
+    const int64_t m = r * bv.mol_stride + j;
+    double *c[3] = { bv.comx + m, bv.comy + m, bv.comz + m };
+    double d[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const double old = *c[k], nw = old * f;
+        d[k] = nw - old;
+        *c[k] = nw;
+    }
+    const int fa = bv.first0[j], na = bv.cnt[j];
+    for (int a = 0; a < na; a++) {
+        const int64_t o = r * bv.atom_stride + fa + a;
+        bv.ax[o] += d[0]; bv.ay[o] += d[1]; bv.az[o] += d[2];
+    }
+    if (rec) {
+        double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_REC;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const int64_t s = r * bv.atom_stride + fa + a;
+            o[3 * a] = bv.ax[s]; o[3 * a + 1] = bv.ay[s]; o[3 * a + 2] = bv.az[s];
+        }
+        o[9] = *c[0]; o[10] = *c[1]; o[11] = *c[2];
+    }
+}
+
 // cos/sin of 2 pi c / L for the three coordinates of every atom (ewalds.jl:564-569), once.
 // ph[r][l][0..5] = cos x, sin x, cos y, sin y, cos z, sin z
 __global__ void k_atom_phases(BatchView bv, double *ph)

@@ -104,6 +104,11 @@ class Context:
     def synchronize(self):
         check(self._L.mmc_ctx_synchronize(self._h))
 
+    def volume_change(self, new_box, new_kappa):
+        """Device part of an NPT volume move (volumeChange.jl:59-80): rescale + rebuild tables."""
+        check(self._L.mmc_volume_change(self._h, float(new_box), float(new_kappa)))
+        self.box = float(new_box)
+
     # -- a6 ------------------------------------------------------------------------------------
     def prepare_ewald(self, kappa, nk, k_sq_max, box, factor):
         n = C.c_int64()
@@ -295,6 +300,9 @@ class Batch:
 
     def set_option(self, key, value):
         check(self._L.mmc_batch_set_option(self._h, key.encode(), int(value)))
+
+    def volume_change(self, new_box, new_kappa):
+        check(self._L.mmc_batch_volume_change(self._h, float(new_box), float(new_kappa)))
 
     def qq_table(self, r2):
         r2 = _f64(r2).ravel()
