@@ -49,6 +49,24 @@ def test_vector1D_reference_semantics():
         assert vector1D(c1, c2, L) == d
 
 
+def test_branch_free_minimum_image_is_bit_identical():
+    """The kernels evaluate vector1D as d - copysign(box, d) under |d| < box - |d|
+    (csrc/mmc_device.hpp); it must equal the reference's two-branch form bit for bit, ties and
+    signed zeros included."""
+    rng = np.random.default_rng(1)
+    L = 30.0
+    c1 = np.concatenate([rng.random(20000) * L, [0.0, 0.0, 15.0, 7.5, 30.0, -0.0, 3.0, 1e-300]])
+    c2 = np.concatenate([rng.random(20000) * L, [15.0, 30.0, 0.0, 22.5, 0.0, 0.0, 3.0, -1e-300]])
+    c1 = np.concatenate([c1, c1 - 1.2, c1 + 0.7])          # atoms may sit slightly outside the box
+    c2 = np.concatenate([c2, c2 + 0.9, c2 - 1.1])
+    d = c2 - c1
+    ad = np.abs(d)
+    fast = np.where(ad < (L - ad), d, d - np.copysign(L, d))
+    ref = np.array([orc.vector1D(float(x), float(y), L) for x, y in zip(c1, c2)])
+    assert np.array_equal(fast, ref)
+    assert np.array_equal(np.signbit(fast), np.signbit(ref))
+
+
 def test_prepare_ewald_kvectors():
     ew = orc.Ewald(5.6 / 30.0, 5, 27, 30.0)
     assert ew.NKVECS == 337                       # strict k^2 < 27 (ewalds.jl:61,76), not 353
