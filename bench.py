@@ -128,10 +128,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # one process per GPU.  MMC_DIST_BACKEND=gloo (rehearsal of the N>1 path on a box with fewer
+    # GPUs than ranks: ranks then share devices and the reduction runs on CPU tensors)
+    backend = os.environ.get("MMC_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
+    red_device = "cuda" if backend == "nccl" else "cpu"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":  # RCCL over xGMI
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import common
     from metropolismontecarlo_amd import sharding, structs
@@ -186,8 +195,8 @@ def main():
                  overlaps=st["overlaps"], energy_sum=float(energies.sum()),
                  kernel_ms=st["kernel_ms"], launches=st["launches"])
     d = dist if world > 1 else None
-    red, elapsed_max = sharding.reduce_observables(local, elapsed, d, device="cuda")
-    _, t_full_max = sharding.reduce_observables(local, t_full, d, device="cuda")
+    red, elapsed_max = sharding.reduce_observables(local, elapsed, d, device=red_device)
+    _, t_full_max = sharding.reduce_observables(local, t_full, d, device=red_device)
     total_moves = red["moves"]
 
     if rank == 0:
