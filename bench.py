@@ -107,7 +107,8 @@ def main():
     ap.add_argument("--replicas", type=int, default=16384, help="replicas per GPU")
     ap.add_argument("--groups", type=int, default=2, help="replica groups pipelined per GPU")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
-    ap.add_argument("--threads", type=int, default=8, help="host threads per GPU for the accept/reject")
+    ap.add_argument("--threads", type=int, default=0,
+                    help="host threads per GPU for the accept/reject (0 = min(8, cores / ranks))")
     ap.add_argument("--kernel", type=int, default=1, help="1 = LDS-tiled kernel, 0 = generic")
     ap.add_argument("--zero-copy-moves", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -123,6 +124,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if args.threads <= 0:
+        # every rank spins its own worker threads: never oversubscribe the node's cores
+        cores = len(os.sched_getaffinity(0))
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        args.threads = max(1, min(8, (cores - local_world) // max(local_world, 1)))
 
     import torch
     import torch.distributed as dist
@@ -220,7 +226,8 @@ def main():
             "config": {"workload": "SPC/E 750 molecules NVT 298.15 K, full Ewald (337 k), "
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
-                       "groups_per_gpu": args.groups, "parallelism": f"replicas x{world}"},
+                       "groups_per_gpu": args.groups, "host_threads_per_gpu": args.threads,
+                       "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),
             "overlaps": int(red["overlaps"]),
             "energy_mean_per_replica": red["energy_sum"] / (R * world),
