@@ -209,7 +209,7 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      H2D copy on the stream (lower latency for one replica, default 0) */
 int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
 /* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
- * r^2 in (0, 1024): lets a test bound its error against an exact evaluation. */
+ * r^2 in (0, 256): lets a test bound its error against an exact evaluation. */
 int32_t mmc_batch_qq_table(mmc_batch *b, const double *r2, int64_t n, double *out);
 /* Settle the last outstanding proposals without evaluating new ones. */
 int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
@@ -240,6 +240,30 @@ typedef struct {
 /* energies: in/out running total energy per replica (R doubles), as `total.energy` (:599). */
 int32_t mmc_batch_run(mmc_batch *b, const mmc_run_params *p, double *energies,
                       mmc_run_stats *stats);
+
+/* Per-chain bookkeeping of Loop(): running totals, block-average accumulators and the two
+ * step-size controllers.  One per replica; persists across mmc_batch_run_chains calls. */
+typedef struct {
+    double dr_max, dphi_max;       /* totProps.dr_max / totProps.dphi_max  (Ewald/main.jl:523,536) */
+    double energy, virial;         /* total.energy, total.virial           (Ewald/main.jl:599-601) */
+    double avg_energy, avg_virial; /* averages.energy / .virial: the running total added after
+                                      EVERY trial move, accepted or not    (Ewald/main.jl:606-625) */
+    int64_t steps_taken;           /* totProps.totalStepsTaken             (Ewald/main.jl:641) */
+    int64_t overlaps;              /* ovr_count                            (Ewald/main.jl:595-597) */
+    /* trans_moves / rot_moves :: Moves (Ewald/structs.jl), fields as used by Adjust! */
+    int64_t trans_naccepp, trans_attempp, trans_naccept, trans_attempt;
+    int64_t rot_naccepp, rot_attempp, rot_naccept, rot_attempt;
+    double trans_set_value, rot_set_value; /* target acceptance ratios (Moves.set_value) */
+} mmc_chain;
+
+/* As mmc_batch_run, with every chain carrying its own step sizes and bookkeeping: p->dr_max and
+ * p->dphi_max are ignored, chains[r].energy replaces energies[r].  After the trial move of the
+ * last molecule of a sweep, Adjust!(trans_moves, box) and Adjust_rot!(rot_moves, box) run for the
+ * chain exactly as at the end of Loop()'s inner loop (Ewald/main.jl:645-651, adjust.jl:1-83);
+ * a controller that saw no attempt since its last call is left alone (the reference would divide
+ * 0/0 there).  adjust = 0 keeps the step sizes fixed. */
+int32_t mmc_batch_run_chains(mmc_batch *b, const mmc_run_params *p, mmc_chain *chains,
+                             int32_t adjust, mmc_run_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -7,6 +7,8 @@ library's message.
 import ctypes as C
 import os
 
+import numpy as np
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmc_hip.so")
 
@@ -61,6 +63,14 @@ class RunStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+# mmc_chain as a numpy record: one row per replica, passed by pointer
+CHAIN_DTYPE = np.dtype([("dr_max", "f8"), ("dphi_max", "f8"), ("energy", "f8"), ("virial", "f8"),
+                        ("avg_energy", "f8"), ("avg_virial", "f8"), ("steps_taken", "i8"),
+                        ("overlaps", "i8"), ("trans_naccepp", "i8"), ("trans_attempp", "i8"),
+                        ("trans_naccept", "i8"), ("trans_attempt", "i8"), ("rot_naccepp", "i8"),
+                        ("rot_attempp", "i8"), ("rot_naccept", "i8"), ("rot_attempt", "i8"),
+                        ("trans_set_value", "f8"), ("rot_set_value", "f8")])
+
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
 _i32p = C.POINTER(C.c_int32)
@@ -112,6 +122,7 @@ SIGNATURES = {
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
+    "mmc_batch_run_chains": [_vp, C.POINTER(RunParams), _vp, C.c_int32, C.POINTER(RunStats)],
 }
 _RESTYPE = {"mmc_last_error": C.c_char_p, "mmc_version": C.c_char_p}
 

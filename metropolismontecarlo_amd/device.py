@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import Move, MoveResult, RunParams, RunStats, Totals, check
+from ._lib import CHAIN_DTYPE, Move, MoveResult, RunParams, RunStats, Totals, check
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
@@ -318,3 +318,25 @@ class Batch:
         e = np.zeros(self.R) if energies is None else _f64(energies).copy()
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
         return e, st.asdict()
+
+    def new_chains(self, energies, virials=None, dr_max=0.15, dphi_max=0.05, set_value=0.5):
+        """One mmc_chain record per replica (numpy structured array, _lib.CHAIN_DTYPE): the
+        bookkeeping Loop() keeps in total / averages / trans_moves / rot_moves / totProps."""
+        c = np.zeros(self.R, dtype=CHAIN_DTYPE)
+        c["dr_max"], c["dphi_max"] = dr_max, dphi_max
+        c["energy"] = energies
+        c["virial"] = 0.0 if virials is None else virials
+        c["trans_set_value"] = c["rot_set_value"] = set_value
+        return c
+
+    def run_chains(self, chains, n_steps, temperature, seed, adjust=True, n_groups=2, n_parts=0,
+                   time_kernels=False, n_threads=1):
+        """mmc_batch_run_chains: `chains` (from new_chains) is updated in place."""
+        if chains.dtype != CHAIN_DTYPE or chains.shape != (self.R,) or not chains.flags.c_contiguous:
+            raise ValueError("chains must be the array returned by new_chains()")
+        p = RunParams(float(temperature), 0.0, 0.0, int(seed), int(n_steps), int(n_groups),
+                      int(n_parts), int(bool(time_kernels)), int(n_threads))
+        st = RunStats()
+        check(self._L.mmc_batch_run_chains(self._h, C.byref(p), chains.ctypes.data_as(C.c_void_p),
+                                           int(bool(adjust)), C.byref(st)))
+        return st.asdict()

@@ -55,6 +55,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Totals) == 64
     assert C.sizeof(_lib.RunParams) == 56
     assert C.sizeof(_lib.RunStats) == 80
+    assert _lib.CHAIN_DTYPE.itemsize == 144        # mmc_chain: 18 eight-byte fields
 
 
 def test_header_cites_reference_lines():

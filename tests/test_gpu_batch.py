@@ -251,3 +251,65 @@ def test_engine_molecules_stay_rigid():
         assert np.abs(bonds(coords) - bonds(a["coords"])).max() < 1e-9
         assert (com >= 0).all() and (com <= a["box"]).all()   # PBC (boundaries.jl:16-26)
         assert np.abs(coords - a["coords"]).max() > 1e-3        # something moved
+
+
+def test_engine_chains_bookkeeping_and_adjust():
+    """mmc_batch_run_chains: Loop()'s per-chain bookkeeping (main.jl:595-651).  Fixed step sizes
+    reproduce mmc_batch_run bit for bit; the running virial matches a recompute; Adjust! after
+    every sweep matches the host mirror of adjust.jl applied to the same counters."""
+    from metropolismontecarlo_amd import moves
+    from metropolismontecarlo_amd._lib import MMCError
+    from metropolismontecarlo_amd.structs import Moves
+    a = common.nist_arrays(1, "unwrapped")
+    n_mol, R = a["com"].shape[0], 4
+    with make_batch(a, R) as b:
+        t0 = b.potential_ewald()
+        e0 = np.array([t["energy"] for t in t0])
+        v0 = np.array([t["virial"] for t in t0])
+        e_plain, st_plain = b.run(2 * n_mol, 298.15, 0.3, 0.05, seed=5, energies=e0, n_threads=2)
+    with make_batch(a, R) as b:
+        b.potential_ewald()
+        ch = b.new_chains(e0, v0, dr_max=0.3, dphi_max=0.05)
+        st = b.run_chains(ch, 2 * n_mol, 298.15, seed=5, adjust=False, n_threads=2)
+        assert np.array_equal(ch["energy"], e_plain)
+        assert st["trans_accept"] == st_plain["trans_accept"] == ch["trans_naccept"].sum()
+        assert (ch["steps_taken"] == 2 * n_mol).all() and (ch["dr_max"] == 0.3).all()
+        assert (ch["trans_attempt"] + ch["rot_attempt"] == 2 * n_mol).all()
+        assert ch["overlaps"].sum() == st["overlaps"]
+        t1 = b.potential_ewald()
+        for r in range(R):
+            assert rel(ch["energy"][r], t1[r]["energy"]) < 1e-9
+            assert rel(ch["virial"][r], t1[r]["virial"]) < 1e-9
+        mean = ch["avg_energy"] / ch["steps_taken"]      # block average of the running total
+        assert (mean < np.maximum(e0, ch["energy"]) + 5e4).all()
+        assert (mean > np.minimum(e0, ch["energy"]) - 5e4).all()
+        # averages.energy accumulates the running total after every move: one move at a time
+        acc = ch["avg_energy"].copy()
+        for k in range(6):
+            b.run_chains(ch, 1, 298.15, seed=100 + k, adjust=False)
+            acc += ch["energy"]
+        assert np.allclose(ch["avg_energy"], acc, rtol=1e-14)
+
+    with make_batch(a, R) as b:
+        b.potential_ewald()
+        ch = b.new_chains(e0, v0, dr_max=2.5, dphi_max=1.5, set_value=0.5)  # far too large
+        mirror = [(Moves(0, 0, 0, 0, 0.5, 2.5), Moves(0, 0, 0, 0, 0.5, 1.5)) for _ in range(R)]
+        for sweep in range(4):
+            b.run_chains(ch, n_mol, 298.15, seed=50 + sweep, adjust=True, n_threads=3)
+            for r in range(R):
+                mt, mr = mirror[r]
+                mt.naccept, mt.attempt = int(ch["trans_naccept"][r]), int(ch["trans_attempt"][r])
+                mr.naccept, mr.attempt = int(ch["rot_naccept"][r]), int(ch["rot_attempt"][r])
+                moves.Adjust(mt, a["box"])
+                moves.Adjust_rot(mr, a["box"])
+                assert ch["dr_max"][r] == mt.d_max and ch["dphi_max"][r] == mr.d_max
+                assert ch["trans_attempp"][r] == mt.attempp and ch["rot_naccepp"][r] == mr.naccepp
+        assert (ch["dr_max"] < 2.5).all()     # acceptance at 2.5 A is far below 50 %: shrunk
+        # a partial sweep does not trigger the controller
+        before = ch["dr_max"].copy()
+        b.run_chains(ch, n_mol - 1, 298.15, seed=99, adjust=True)
+        assert np.array_equal(ch["dr_max"], before)
+        bad = ch.copy()
+        bad["trans_set_value"][1] = 0.0
+        with pytest.raises(MMCError):
+            b.run_chains(bad, 1, 298.15, seed=1)
