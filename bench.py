@@ -104,19 +104,25 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=600)
     ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--replicas", type=int, default=16384, help="replicas per GPU")
+    ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
     ap.add_argument("--groups", type=int, default=2, help="replica groups pipelined per GPU")
     ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
     ap.add_argument("--threads", type=int, default=0,
-                    help="host threads per GPU for the accept/reject (0 = min(8, cores / ranks))")
+                    help="host threads per GPU for the accept/reject (0 = min(4, cores / ranks))")
     ap.add_argument("--kernel", type=int, default=1, help="1 = LDS-tiled kernel, 0 = generic")
     ap.add_argument("--zero-copy-moves", type=int, default=0)
+    ap.add_argument("--device-moves", type=int, default=1,
+                    help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the 1-replica and 32-replica side measurements")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket launches with HIP events in the timed region")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="bracket every Nth launch of a group with HIP events (an event pair costs "
+                         "~10 us of stream time, so timing every launch slows what it measures)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -128,7 +134,7 @@ def main():
         # every rank spins its own worker threads: never oversubscribe the node's cores
         cores = len(os.sched_getaffinity(0))
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.threads = max(1, min(8, (cores - local_world) // max(local_world, 1)))
+        args.threads = max(1, min(4, (cores - local_world) // max(local_world, 1)))
 
     import torch
     import torch.distributed as dist
@@ -159,6 +165,7 @@ def main():
               5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
     b.set_option("kernel", args.kernel)
     b.set_option("zero_copy_moves", args.zero_copy_moves)
+    b.set_option("device_moves", args.device_moves)
 
     def barrier():
         if world > 1:
@@ -177,17 +184,17 @@ def main():
     # chain r of this rank has global index rank*R + r and draws from stream seed + r (the driver
     # adds r): trajectories depend on the global index only, not on the number of GPUs
     g0 = sharding.shard(R, rank)[0]
-    ev = 0 if args.no_events else 1
+    ev = 0 if args.no_events else max(1, args.event_every)
     energies, _ = b.run(args.warmup, TEMPERATURE, DR_MAX, DPHI_MAX,
                         sharding.replica_seed(g0, phase=0), energies,
                         n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                        n_threads=args.threads)
+                        n_threads=args.threads, n_streams=args.streams)
     barrier()
     t0 = time.perf_counter()
     energies, st = b.run(args.steps, TEMPERATURE, DR_MAX, DPHI_MAX,
                          sharding.replica_seed(g0, phase=1), energies,
                          n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                         n_threads=args.threads)
+                         n_threads=args.threads, n_streams=args.streams)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -227,6 +234,7 @@ def main():
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
                        "groups_per_gpu": args.groups, "host_threads_per_gpu": args.threads,
+                       "move_generation": "device" if args.device_moves else "host",
                        "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),
             "overlaps": int(red["overlaps"]),
@@ -235,8 +243,9 @@ def main():
             "ns_per_full_energy_eval": 1e9 * t_full_max / R,
             "full_energy_evals_per_s": R * world / t_full_max,
         }
-        if ev and launches:
-            t_launch = st["kernel_ms"] * 1e-3 / launches  # rank 0's average launch duration
+        if ev and st["timed_launches"]:
+            # rank 0's average launch duration over the launches that carried events
+            t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
             achieved = bytes_move * replicas_per_launch / t_launch / 1e9
             out["roofline"] = {
                 "kernel": "k_move_eval_fast" if args.kernel == 1 else "k_move_eval",
@@ -244,6 +253,7 @@ def main():
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args, replicas_per_launch),
                 "avg_launch_us": 1e6 * t_launch, "launches": int(launches),
+                "launches_timed_with_events": int(st["timed_launches"]),
                 "algorithmic_bytes_per_move": bytes_move,
                 "moves_per_launch": replicas_per_launch,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
@@ -256,6 +266,7 @@ def main():
                                      ("configs[2] share: 32 replicas per GPU", 32, 2, 2)):
                 b2 = Batch(r2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"],
                            box, 5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
+                b2.set_option("zero_copy_moves", 1)   # latency-bound: no H2D copy in the step
                 e2 = np.array([t["energy"] for t in b2.potential_ewald()])
                 e2, _ = b2.run(200, TEMPERATURE, DR_MAX, DPHI_MAX, SEED, e2, n_groups=g2,
                                n_threads=t2)

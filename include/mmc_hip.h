@@ -206,7 +206,12 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *   "kernel"           1 = LDS-tiled kernel with the erfc(kappa r)/r table (default when every
  *                      molecule has the same atom types and charges), 0 = generic kernel
  *   "zero_copy_moves"  1 = the kernel reads proposals from pinned host memory instead of an
- *                      H2D copy on the stream (lower latency for one replica, default 0) */
+ *                      H2D copy on the stream (lower latency for one replica, default 0)
+ *   "device_moves"     1 = mmc_batch_run / mmc_batch_run_chains generate the trial moves on the
+ *                      device (counter-based Philox4x32-10 keyed by seed + replica and the step
+ *                      number; same move distributions as the host generator, a different random
+ *                      stream): only one flag byte per replica and step crosses PCIe and no host
+ *                      mirror of the coordinates is kept.  Default 0. */
 int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
 /* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
  * r^2 in (0, 256): lets a test bound its error against an exact evaluation. */
@@ -225,8 +230,12 @@ typedef struct {
     int64_t n_steps;     /* trial moves per replica to run */
     int32_t n_groups;    /* replica groups pipelined on separate streams (>=1) */
     int32_t n_parts;     /* workgroups per replica-move (0 = choose) */
-    int32_t time_kernels;/* 1: bracket every launch with HIP events (stats.kernel_ms) */
+    int32_t time_kernels;/* N > 0: bracket every Nth launch of a group with HIP events
+                            (stats.kernel_ms over stats.timed_launches); 0: none */
     int32_t n_threads;   /* host threads sharing the groups (0 or 1 = the calling thread only) */
+    int32_t n_streams;   /* HIP streams the groups are spread over; 0 = choose (one per group with
+                            host proposals, one for all with "device_moves") */
+    int32_t _pad;
 } mmc_run_params;
 
 typedef struct {
@@ -235,7 +244,12 @@ typedef struct {
     double wall_ms;      /* host wall clock over the run */
     double kernel_ms;    /* sum of HIP-event durations of the move kernel (time_kernels) */
     double energy_sum;   /* sum over replicas of the running total energy at the end */
+    int64_t timed_launches; /* launches that contributed to kernel_ms */
 } mmc_run_stats;
+
+/* The driver's counter-based generator, exposed for known-answer tests and for callers that
+ * want to re-derive a chain's draws: Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11). */
+int32_t mmc_philox4x32(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 
 /* energies: in/out running total energy per replica (R doubles), as `total.energy` (:599). */
 int32_t mmc_batch_run(mmc_batch *b, const mmc_run_params *p, double *energies,

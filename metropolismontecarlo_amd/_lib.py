@@ -49,7 +49,8 @@ class RunParams(C.Structure):
     """mmc_run_params"""
     _fields_ = [("temperature", C.c_double), ("dr_max", C.c_double), ("dphi_max", C.c_double),
                 ("seed", C.c_uint64), ("n_steps", C.c_int64), ("n_groups", C.c_int32),
-                ("n_parts", C.c_int32), ("time_kernels", C.c_int32), ("n_threads", C.c_int32)]
+                ("n_parts", C.c_int32), ("time_kernels", C.c_int32), ("n_threads", C.c_int32),
+                ("n_streams", C.c_int32), ("_pad", C.c_int32)]
 
 
 class RunStats(C.Structure):
@@ -57,7 +58,8 @@ class RunStats(C.Structure):
     _fields_ = [("moves", C.c_int64), ("launches", C.c_int64), ("trans_attempt", C.c_int64),
                 ("trans_accept", C.c_int64), ("rot_attempt", C.c_int64),
                 ("rot_accept", C.c_int64), ("overlaps", C.c_int64), ("wall_ms", C.c_double),
-                ("kernel_ms", C.c_double), ("energy_sum", C.c_double)]
+                ("kernel_ms", C.c_double), ("energy_sum", C.c_double),
+                ("timed_launches", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -122,6 +124,7 @@ SIGNATURES = {
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
+    "mmc_philox4x32": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "mmc_batch_run_chains": [_vp, C.POINTER(RunParams), _vp, C.c_int32, C.POINTER(RunStats)],
 }
 _RESTYPE = {"mmc_last_error": C.c_char_p, "mmc_version": C.c_char_p}

@@ -194,12 +194,14 @@ struct FastShared {
     int32_t tflag[MMC_TILE];
     int32_t ljp_ab[9];
     int32_t wcnt[MMC_WAVES];
+    int32_t gflag;
 };
 
 // grid (n_parts, replicas of the group); same part semantics as k_move_eval.
 __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     BatchView bv, double *rec, const double *qq_tab, const int32_t *kpack, FastConsts fc,
-    const MoveRec *cur, const MoveRec *prev, PartOut *out, int n_parts, PairParams pp, int r_base)
+    const MoveRec *cur, const MoveRec *prev, PartOut *out, int n_parts, PairParams pp, int r_base,
+    const uint8_t *flagv, unsigned stamp)
 {
     __shared__ __align__(16) FastShared sm;
 
@@ -222,6 +224,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
         sm.mvw[tid] = reinterpret_cast<const double *>(cur + r)[tid];
     else if (prev && tid >= 32 && tid < 32 + MV_WORDS)
         sm.pvw[tid - 32] = reinterpret_cast<const double *>(prev + r)[tid - 32];
+    else if (tid == 63)
+        sm.gflag = flagv ? (int)flagv[r] : -1; // device-generated records: flags travel apart
     else if (tid >= 64 && tid < 73) {
         const int t = tid - 64;
         sm.qq9[t] = fc.qq9[t];
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     __syncthreads();
 
     const int2 hdr = *reinterpret_cast<const int2 *>(&sm.mvw[0]);
-    const int i0 = hdr.x - 1, flags = hdr.y;
+    const int i0 = hdr.x - 1, flags = sm.gflag >= 0 ? sm.gflag : hdr.y;
     const bool commit = prev && (flags & 1);
     const int scur = (flags >> 1) & 1;
     const int pend = commit ? reinterpret_cast<const int *>(&sm.pvw[0])[0] - 1 : -1;
@@ -473,16 +477,12 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     __syncthreads();
     double v[7] = { a_lj0, a_lj1, a_v0, a_v1, a_q0, a_q1, a_rec };
     block_sum_wide<7>(v, sm.tile, sm.red, ovl0 | (ovl1 << 1), sm.wcnt);
-    if (tid == 0) {
+    if (tid == 0) { // sm.red[0..6] are already in PartOut order
         const int of = sm.wcnt[0] | sm.wcnt[1] | sm.wcnt[2] | sm.wcnt[3];
-        PartOut po;
-        po.lj_pot[0] = sm.red[0]; po.lj_pot[1] = sm.red[1];
-        po.lj_vir[0] = sm.red[2]; po.lj_vir[1] = sm.red[3];
-        po.qq_pot[0] = sm.red[4]; po.qq_pot[1] = sm.red[5];
-        po.recip = sm.red[6];
-        po.ovl[0] = of & 1; po.ovl[1] = (of >> 1) & 1;
-        out[(int64_t)r * n_parts + part] = po;
+        sm.red[7] = pack_ovl(of & 1, (of >> 1) & 1, stamp);
     }
+    __syncthreads();
+    store_part(out + (int64_t)r * n_parts + part, sm.red, tid);
 }
 
 // settle for the record layout: as k_settle, plus rec.

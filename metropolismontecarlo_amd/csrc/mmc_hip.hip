@@ -2,6 +2,7 @@
 // C ABI: include/mmc_hip.h.  No torch types, no CPU fallback: without a HIP device every entry
 // point that needs one returns MMC_ERR_HIP.
 #include "mmc_host.hpp"
+#include "mmc_propose.hpp"
 
 #include "mmc_system.inc"
 #include "mmc_ctx.inc"

@@ -258,18 +258,42 @@ struct MoveRec {
 struct PartOut {
     double lj_pot[2], lj_vir[2], qq_pot[2]; // [old, new] raw sums of this workgroup's j-range
     double recip;                           // sum_k cfac (|S_new|^2 - |S_old|^2), no factor
-    int32_t ovl[2];
+    int32_t ovl[2];                         // overlap of the old / new state; ovl[1] also carries
+                                            // the launch stamp: (stamp << 1) | overlap_new
 };
+static_assert(sizeof(PartOut) == 64, "PartOut is one 64-byte line");
+
+// A PartOut leaves the workgroup as ONE 64-byte store (4 lanes x 16 B of one instruction) into
+// pinned host memory.  The driver stamps every launch with its number and polls ovl[1]: the
+// moment a record carries the expected stamp it is complete and may be consumed -- no event, no
+// stream synchronisation, and the host starts on the first results while the launch still runs.
+// `w8`: the record as 8 words in LDS (7 sums + the two ints), complete before the call.
+#define MMC_STAMP_MASK 0x3fffffffu
+__device__ inline void store_part(PartOut *dst, const double *w8, int tid)
+{
+    if (tid < 4)
+        reinterpret_cast<double2 *>(dst)[tid] = make_double2(w8[2 * tid], w8[2 * tid + 1]);
+}
+
+__device__ inline double pack_ovl(int o0, int o1, unsigned stamp)
+{
+    const unsigned lo = (unsigned)(o0 & 1), hi = ((stamp & MMC_STAMP_MASK) << 1) | (unsigned)(o1 & 1);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // grid (n_parts, R).  n_parts == 1: the workgroup scans all molecules and then does the
 // reciprocal part.  n_parts > 1: parts 0..n_parts-2 split the molecule range, the last part does
 // the reciprocal part -- this is how a small replica count still fills 256 CUs.
 // `rec`: the record array of homogeneous systems (kept in step by the commit) or NULL.
+// `flagv`: when not NULL the per-replica flag byte comes from here instead of the record header
+// (device-generated records are written before the accept decision of the previous step exists).
 __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const MoveRec *cur,
                                                          const MoveRec *prev, PartOut *out,
                                                          int n_parts, PairParams pp, int r_base,
-                                                         double *rec)
+                                                         double *rec, const uint8_t *flagv,
+                                                         unsigned stamp)
 {
+    __shared__ __align__(16) double pobuf[8];
     __shared__ Chosen ch;
     __shared__ Pending pd;
     __shared__ int32_t list[MMC_LIST_CAP];
@@ -280,7 +304,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
     const int r = r_base + blockIdx.y, part = blockIdx.x, tid = threadIdx.x;
     const SysView s = sys_view(bv, r);
     const MoveRec *mv = cur + r;
-    const int flags = mv->flags;
+    const int flags = flagv ? (int)flagv[r] : mv->flags;
     const bool commit = prev && (flags & 1);
     const int scur = (flags >> 1) & 1;
     const int i0 = mv->mol - 1;
@@ -384,8 +408,15 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
         if (tid == 0)
             po.recip = tot[0];
     }
-    if (tid == 0)
-        out[(int64_t)r * n_parts + part] = po;
+    if (tid == 0) {
+        pobuf[0] = po.lj_pot[0]; pobuf[1] = po.lj_pot[1];
+        pobuf[2] = po.lj_vir[0]; pobuf[3] = po.lj_vir[1];
+        pobuf[4] = po.qq_pot[0]; pobuf[5] = po.qq_pot[1];
+        pobuf[6] = po.recip;
+        pobuf[7] = pack_ovl(po.ovl[0], po.ovl[1], stamp);
+    }
+    __syncthreads();
+    store_part(out + (int64_t)r * n_parts + part, pobuf, tid);
 }
 
 // ---- small state updates -----------------------------------------------------------------------

@@ -311,9 +311,10 @@ class Batch:
         return out
 
     def run(self, n_steps, temperature, dr_max, dphi_max, seed, energies=None, n_groups=2,
-            n_parts=0, time_kernels=False, n_threads=1):
+            n_parts=0, time_kernels=False, n_threads=1, n_streams=0):
         p = RunParams(float(temperature), float(dr_max), float(dphi_max), int(seed), int(n_steps),
-                      int(n_groups), int(n_parts), int(bool(time_kernels)), int(n_threads))
+                      int(n_groups), int(n_parts), int(time_kernels), int(n_threads),
+                      int(n_streams), 0)
         st = RunStats()
         e = np.zeros(self.R) if energies is None else _f64(energies).copy()
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
@@ -330,12 +331,12 @@ class Batch:
         return c
 
     def run_chains(self, chains, n_steps, temperature, seed, adjust=True, n_groups=2, n_parts=0,
-                   time_kernels=False, n_threads=1):
+                   time_kernels=False, n_threads=1, n_streams=0):
         """mmc_batch_run_chains: `chains` (from new_chains) is updated in place."""
         if chains.dtype != CHAIN_DTYPE or chains.shape != (self.R,) or not chains.flags.c_contiguous:
             raise ValueError("chains must be the array returned by new_chains()")
         p = RunParams(float(temperature), 0.0, 0.0, int(seed), int(n_steps), int(n_groups),
-                      int(n_parts), int(bool(time_kernels)), int(n_threads))
+                      int(n_parts), int(time_kernels), int(n_threads), int(n_streams), 0)
         st = RunStats()
         check(self._L.mmc_batch_run_chains(self._h, C.byref(p), chains.ctypes.data_as(C.c_void_p),
                                            int(bool(adjust)), C.byref(st)))

@@ -53,8 +53,8 @@ def test_struct_layouts_match_header():
     assert _lib.Move.com_new.offset == 8 and _lib.Move.atoms_new.offset == 32
     assert C.sizeof(_lib.MoveResult) == 40
     assert C.sizeof(_lib.Totals) == 64
-    assert C.sizeof(_lib.RunParams) == 56
-    assert C.sizeof(_lib.RunStats) == 80
+    assert C.sizeof(_lib.RunParams) == 64
+    assert C.sizeof(_lib.RunStats) == 88
     assert _lib.CHAIN_DTYPE.itemsize == 144        # mmc_chain: 18 eight-byte fields
 
 

@@ -313,3 +313,135 @@ def test_engine_chains_bookkeeping_and_adjust():
         bad["trans_set_value"][1] = 0.0
         with pytest.raises(MMCError):
             b.run_chains(bad, 1, 298.15, seed=1)
+
+
+# ---- device-side move generation ------------------------------------------------
+@pytest.mark.parametrize("R,groups,parts,threads,kernel,zero_copy",
+                         [(1, 1, 0, 1, 1, 0), (7, 2, 0, 2, 1, 0), (16, 3, 1, 3, 1, 1),
+                          (8, 2, 4, 2, 0, 0)])
+def test_device_moves_running_total_vs_recompute(R, groups, parts, threads, kernel, zero_copy, orc):
+    """Same invariant as test_engine_running_total_vs_recompute with the proposals drawn on the
+    device: the move kernel, the commit and S(k) see exactly the coordinates k_propose wrote."""
+    a = common.nist_arrays(1, "unwrapped")
+    n_steps = 260
+    with make_batch(a, R) as b:
+        b.set_option("kernel", kernel)
+        b.set_option("device_moves", 1)
+        b.set_option("zero_copy_moves", zero_copy)
+        e0 = np.array([t["energy"] for t in b.potential_ewald()])
+        e1, st = b.run(n_steps, 298.15, 0.316555789, 0.05, seed=4242, energies=e0,
+                       n_groups=groups, n_parts=parts, n_threads=threads)
+        assert st["moves"] == n_steps * R
+        assert st["trans_attempt"] + st["rot_attempt"] == n_steps * R
+        assert 0.3 < st["trans_attempt"] / (n_steps * R) < 0.7      # chose_move < 0.5
+        acc = st["trans_accept"] + st["rot_accept"]
+        assert 0.2 * n_steps * R < acc < n_steps * R
+        S_inc = [b.get_replica(r)[2] for r in range(R)]
+        t1 = b.potential_ewald()
+        for r in range(R):
+            assert rel(e1[r], t1[r]["energy"]) < 1e-9, (r, e1[r], t1[r]["energy"])
+            S_new = b.get_replica(r)[2]
+            assert np.abs(S_inc[r] - S_new).max() < 1e-9 * np.abs(S_new).max()
+        if R > 1:
+            assert len({round(x, 6) for x in e1}) > 1
+        com, coords, _ = b.get_replica(R - 1)
+        s = common.oracle_system(dict(a, com=com, coords=coords))
+        to = orc.potential_ewald(s, orc.Ewald(5.6 / s.box, 5, 27, s.box), RCUT, RCUT)
+        assert rel(t1[R - 1]["energy"], to["energy"]) < TOL
+        # back to host-side proposals on the same batch: the host mirror is refreshed first
+        b.set_option("device_moves", 0)
+        e2, _ = b.run(120, 298.15, 0.316555789, 0.05, seed=5, energies=e1, n_groups=groups,
+                      n_threads=threads)
+        t2 = b.potential_ewald()
+        for r in range(R):
+            assert rel(e2[r], t2[r]["energy"]) < 1e-9
+
+
+def test_device_moves_distribution_of_one_step():
+    """One step from a known state: an accepted translation displaces the COM by at most
+    dr_max/2 per axis with the atoms following rigidly (auxillary.jl:94-103), an accepted
+    rotation keeps the COM and turns the molecule by at most dphi_max (quaternions.jl:158-182)."""
+    a = common.nist_arrays(2, "unwrapped")
+    R, dr, dphi, box = 400, 0.3, 0.2, a["box"]
+    with make_batch(a, R) as b:
+        b.set_option("device_moves", 1)
+        b.recip_long()
+        # T -> infinity: Metropolis accepts (nearly) everything, so the accepted displacements
+        # are the proposal distribution itself, not biased by the local energy gradient
+        _, st = b.run(1, 1.0e12, dr, dphi, seed=77, n_threads=2)
+        c0, x0 = a["com"][0], a["coords"][:3]
+        n_t = n_r = 0
+        zs, angles = [], []
+        for r in range(R):
+            com, coords, _ = b.get_replica(r)
+            assert np.array_equal(com[1:], a["com"][1:]) and np.array_equal(coords[3:], a["coords"][3:])
+            if np.array_equal(coords[:3], x0):
+                continue                                  # rejected
+            d = com[0] - c0
+            if np.abs(d).max() > 0:                       # translation
+                n_t += 1
+                dw = d - box * np.round(d / box)
+                assert np.abs(dw).max() <= dr / 2 + 1e-12
+                assert (com[0] >= 0).all() and (com[0] <= box).all()
+                assert np.abs((coords[:3] - x0) - d).max() < 1e-12
+                zs.append(dw / dr)
+            else:                                         # rotation about the COM
+                n_r += 1
+                o0, o1 = x0 - c0, coords[:3] - c0
+                assert np.abs(np.linalg.norm(o1, axis=1) - np.linalg.norm(o0, axis=1)).max() < 1e-12
+                # rotation angle from the trace of R, R = o1^T pinv(o0^T) on the molecular frame
+                f0 = np.stack([o0[0], o0[1], np.cross(o0[0], o0[1])])
+                f1 = np.stack([o1[0], o1[1], np.cross(o1[0], o1[1])])
+                Rm = np.linalg.solve(f0, f1).T
+                assert np.allclose(Rm @ Rm.T, np.eye(3), atol=1e-9)
+                ang = np.arccos(np.clip((np.trace(Rm) - 1) / 2, -1, 1))
+                assert ang <= dphi + 1e-9
+                angles.append(ang)
+        assert n_t == st["trans_accept"] and n_r == st["rot_accept"]
+        assert n_t > 150 and n_r > 150 and n_t + n_r >= R - 2
+        zs = np.array(zs)                                  # uniform on (-1/2, 1/2): sigma of the
+        assert abs(zs.mean()) < 0.06 and zs.min() < -0.45 and zs.max() > 0.45   # mean is 0.013
+        assert abs(zs.std() - 12 ** -0.5) < 0.03
+        assert max(angles) > 0.8 * dphi
+
+
+def test_device_moves_deterministic_and_statistically_like_host_moves():
+    a = common.nist_arrays(1, "unwrapped")
+    res = []
+    for groups, threads in ((1, 1), (3, 2)):
+        with make_batch(a, 12) as b:
+            b.set_option("device_moves", 1)
+            b.recip_long()
+            res.append(b.run(200, 298.15, 0.316555789, 0.05, seed=9, n_groups=groups, n_parts=1,
+                             n_threads=threads))
+    assert np.array_equal(res[0][0], res[1][0])       # counter-based draws: grouping cannot matter
+    for key in ("trans_accept", "rot_accept", "trans_attempt", "overlaps"):
+        assert res[0][1][key] == res[1][1][key]
+    with make_batch(a, 12) as b:
+        b.recip_long()
+        _, host = b.run(200, 298.15, 0.316555789, 0.05, seed=9, n_parts=1)
+    dev = res[0][1]
+    ratio = lambda s: (s["trans_accept"] + s["rot_accept"]) / s["moves"]
+    assert abs(ratio(dev) - ratio(host)) < 0.05
+
+
+def test_device_moves_chains_adjust():
+    a = common.nist_arrays(1, "unwrapped")
+    n_mol, R = a["com"].shape[0], 3
+    with make_batch(a, R) as b:
+        b.set_option("device_moves", 1)
+        t0 = b.potential_ewald()
+        ch = b.new_chains([t["energy"] for t in t0], [t["virial"] for t in t0], dr_max=2.5,
+                          dphi_max=1.5)
+        b.run_chains(ch, 4 * n_mol, 298.15, seed=21, adjust=True, n_threads=2)
+        assert (ch["dr_max"] < 1.5).all() and (ch["dphi_max"] < 1.5).all()
+        assert (ch["steps_taken"] == 4 * n_mol).all()
+        t1 = b.potential_ewald()
+        for r in range(R):
+            assert rel(ch["energy"][r], t1[r]["energy"]) < 1e-9
+            assert rel(ch["virial"][r], t1[r]["virial"]) < 1e-9
+        # the shrunken step sizes reached the device: every molecule moved less than the initial box
+        com, coords, _ = b.get_replica(0)
+        d = com - a["com"]
+        d -= a["box"] * np.round(d / a["box"])
+        assert np.abs(d).max() < 4 * 1.25 + 1e-9

@@ -65,3 +65,20 @@ def test_bench_byte_model():
     assert bench.algorithmic_bytes_per_move(750, 30.0) == pytest.approx(78.7e3, rel=2e-3)
     assert bench.algorithmic_bytes_full_eval(750) == pytest.approx(111.1e3, rel=2e-3)
     assert bench.algorithmic_bytes_per_move(1000, 31.1448) == pytest.approx(95.5e3, rel=5e-3)
+
+
+def test_philox4x32_known_answers():
+    """The driver's counter-based generator against the Random123 known-answer vectors
+    (philox4x32, 10 rounds: zero, all-ones and the digits-of-pi counter/key)."""
+    import ctypes as C
+    from metropolismontecarlo_amd import _lib
+    L = _lib.lib()
+
+    def ph(ctr, key):
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        assert L.mmc_philox4x32(c, k, o) == 0
+        return list(o)
+    assert ph([0] * 4, [0] * 2) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
