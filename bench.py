@@ -9,16 +9,18 @@ Ewald/coord750.txt, committed as tests/golden/spce_nist.npz), NVT at 298.15 K, f
 (kappa = 5.6/L, 337 k-vectors), fp64, r_cut = 10 A.  R independent replicas per GPU (one Markov
 chain each, RNG stream seed 11234 + global replica index); replicas shard across ranks with no
 data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of every
-replica of the rank: one fused launch of k_move_eval (2x LJ_poly_dU + 2x EwaldShort + RecipMove +
-commit of the previous accepted move) per replica group, followed by the sequential Metropolis
-accept/reject on the host (native C++ driver, mmc_batch_run).  Inputs are resident in HBM before
-the timed region; per step only the proposals (104 B per replica) travel to the device.
+replica of the rank: one fused launch of k_move_eval_fast (2x LJ_poly_dU + 2x EwaldShort +
+RecipMove + commit of the previous accepted move) per replica group, followed by the sequential
+Metropolis accept/reject on the host (native C++ driver, mmc_batch_run).  Inputs are resident in
+HBM before the timed region; the trial moves are drawn on the device (k_propose, Philox4x32-10),
+so per step one flag byte per replica travels to the device and 64 B of results come back
+(--device-moves 0: the host draws the moves and sends 200 B per replica and step).
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline      dominant kernel k_move_eval: algorithmic bytes per launch (SURVEY.md section 8d:
-                78.7 KB per trial move at 750 molecules x replicas per launch) / average launch
+  roofline      dominant kernel k_move_eval_fast: algorithmic bytes per launch (SURVEY.md section
+                8d: 78.7 KB per trial move at 750 molecules x replicas per launch) / average launch
                 duration measured with HIP events on the kernel's own stream inside the timed
-                region, against the 8 TB/s HBM peak.
+                region (every --event-every'th launch), against the 8 TB/s HBM peak.
   cpu_baseline  the CPU oracle (a single-threaded C port of the reference's Julia code path; the
                 Julia reference itself cannot run here) timed on this host on the same workload.
 """
