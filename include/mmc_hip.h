@@ -158,6 +158,22 @@ int32_t mmc_trial_move(mmc_ctx *ctx, int64_t i, const double *com_new, const dou
 int32_t mmc_accept_move(mmc_ctx *ctx);
 int32_t mmc_reject_move(mmc_ctx *ctx);
 
+/* ---- single-precision tolerance study (BASELINE.json configs[4]: Wolf vs Ewald, fp32 vs fp64) ---
+ * Not a reference interface: the reference is fp64 only.  The same terms as mmc_lj_poly_du /
+ * mmc_ewald_real / mmc_recip_long / mmc_recip_move, evaluated from coordinates rounded to fp32 with
+ * fp32 arithmetic; mixed = 0: fp32 accumulators, 1: fp64 accumulators.
+ * total: out = { LJ energy, LJ virial, real-space Coulomb (factor in), reciprocal (factor in),
+ *                number of overlapping molecules, 0 } -- the summed terms of potential()
+ *        (energy.jl:946-1032); add mmc_ewald_self for the Ewald total or the Wolf constants of
+ *        mmc_potential_wolf (.self) for the Wolf total.  Also builds the fp32 structure factor.
+ * move:  d = { dLJ, dReal, dRecip } of mmc_trial_move's d[0..2] in fp32 for molecule i (1-based)
+ *        moved to com_new / atoms_new; the device state is not touched. */
+int32_t mmc_study_f32_total(mmc_ctx *ctx, double lj_rcut, double qq_rcut, int32_t mixed,
+                            double out[6]);
+int32_t mmc_study_f32_move(mmc_ctx *ctx, int64_t i, const double *com_new, const double *atoms_new,
+                           double lj_rcut, double qq_rcut, int32_t mixed, double d[3],
+                           int32_t *overlap);
+
 /* ---- replica batch: R independent NVT chains of the same system on one GPU ------------------ */
 typedef struct {
     int32_t mol;         /* 1-based molecule index of this replica's trial move */

@@ -124,6 +124,8 @@ SIGNATURES = {
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
+    "mmc_study_f32_total": [_vp, C.c_double, C.c_double, C.c_int32, _dp],
+    "mmc_study_f32_move": [_vp, _i64, _dp, _dp, C.c_double, C.c_double, C.c_int32, _dp, _i32p],
     "mmc_philox4x32": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "mmc_batch_run_chains": [_vp, C.POINTER(RunParams), _vp, C.c_int32, C.POINTER(RunStats)],
 }

@@ -202,6 +202,24 @@ class Context:
                                      float(qq_rcut), _d(d), C.byref(o)))
         return d, bool(o.value)
 
+    # ---- single-precision tolerance study (not a reference interface) ----
+    def study_f32_total(self, lj_rcut, qq_rcut, mixed=False):
+        """{lj, lj_virial, real, recip, n_overlap}: the summed terms of potential() from fp32
+        coordinates and arithmetic (mixed: fp64 accumulators)."""
+        out = np.zeros(6)
+        check(self._L.mmc_study_f32_total(self._h, float(lj_rcut), float(qq_rcut), int(bool(mixed)),
+                                          _d(out)))
+        return dict(lj=out[0], lj_virial=out[1], real=out[2], recip=out[3], n_overlap=int(out[4]))
+
+    def study_f32_move(self, i, com_new, atoms_new, lj_rcut, qq_rcut, mixed=False):
+        com_new, atoms_new = _f64(com_new).ravel(), _f64(atoms_new).ravel()
+        d = np.zeros(3)
+        o = C.c_int32()
+        check(self._L.mmc_study_f32_move(self._h, int(i), _d(com_new), _d(atoms_new),
+                                         float(lj_rcut), float(qq_rcut), int(bool(mixed)), _d(d),
+                                         C.byref(o)))
+        return d, bool(o.value)
+
     def accept_move(self):
         check(self._L.mmc_accept_move(self._h))
 

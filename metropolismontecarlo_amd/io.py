@@ -114,14 +114,19 @@ def cubic_lattice_water(n_mol, rho, geometry="spce", seed=11234):
     if geometry == "spce":  # O-H 1.0 A, H-O-H 109.47 deg
         r_oh, ang = 1.0, np.deg2rad(109.47)
         masses = np.array([15.9994, 1.008, 1.008])
-    elif geometry == "tip3p":  # tip3p.pdb:3-5 geometry: O-H 0.9572 A, 104.52 deg
-        r_oh, ang = 0.9572, np.deg2rad(104.52)
+    elif geometry == "tip3p":
+        # the three sites of Ewald/tip3p.pdb:3-5 as data (O, H, H; the file's geometry is
+        # O-H 1.000 A, H-O-H 109.5 deg -- not the textbook TIP3P 0.9572 A / 104.52 deg)
+        r_oh = ang = None
         masses = np.array([15.9994, 1.008, 1.008])
     else:
         raise ValueError(geometry)
-    body = np.array([[0.0, 0.0, 0.0],
-                     [r_oh * np.sin(ang / 2), 0.0, r_oh * np.cos(ang / 2)],
-                     [-r_oh * np.sin(ang / 2), 0.0, r_oh * np.cos(ang / 2)]])
+    if r_oh is None:
+        body = np.array([[-4.369, 0.061, -0.042], [-3.370, 0.049, 0.000], [-4.743, -0.180, 0.854]])
+    else:
+        body = np.array([[0.0, 0.0, 0.0],
+                         [r_oh * np.sin(ang / 2), 0.0, r_oh * np.cos(ang / 2)],
+                         [-r_oh * np.sin(ang / 2), 0.0, r_oh * np.cos(ang / 2)]])
     body = body - (body * masses[:, None]).sum(0) / masses.sum()
     rng = np.random.default_rng(seed)
     q = rng.normal(size=(n_mol, 4))
