@@ -73,28 +73,17 @@ def pmc_traffic(args, moves_per_launch):
     return t["bytes_per_launch"]
 
 
-def cpu_baseline(a, budget_s):
-    """Time the oracle (C port, 1 thread) on the same workload: Loop()'s hot-path calls for
-    successive molecules with small rigid translations, for about `budget_s` seconds."""
+def cpu_baseline(a, budget_s, n_threads=1):
+    """Time the oracle (C port of the reference path) on the same workload: Loop()'s hot-path
+    calls for successive molecules with small rigid translations, in a C loop
+    (orc_bench_trial_moves; n_threads independent chains, one per thread) for `budget_s` seconds.
+    Returns (moves/s, moves, seconds, seconds of one full energy evaluation on one thread)."""
     import common
     from oracle import oracle as orc
     s = common.oracle_system(a)
     ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
     orc.recip_long(ew, s.coords, s.charge, s.box)
-    rng = np.random.default_rng(SEED)
-    n = 0
-    t0 = time.perf_counter()
-    while True:
-        i = n % s.n_mol + 1
-        d = (rng.random(3) - 0.5) * DR_MAX
-        cn = s.com[i - 1] + d
-        an = s.coords[3 * (i - 1):3 * i] + d
-        orc.trial_move(i, s, ew, RCUT, RCUT, cn, an)
-        ew.sumQExpNew[:] = ew.sumQExpOld  # reject: main.jl:628
-        n += 1
-        if n % 50 == 0 and time.perf_counter() - t0 > budget_s:
-            break
-    dt = time.perf_counter() - t0
+    n, dt = orc.bench_trial_moves(s, ew, RCUT, RCUT, DR_MAX, SEED, n_threads, budget_s)
     t1 = time.perf_counter()
     orc.potential_ewald(s, ew, RCUT, RCUT)
     t_full = time.perf_counter() - t1
@@ -260,6 +249,17 @@ def main():
                 "moves_per_launch": replicas_per_launch,
                 "frac_of_measured_copy_peak_6290": achieved / 6290.0,
             }
+        # raw work counts: per trial move 2 states x (N_mol - 1) COM tests,
+        # 2 x 9 x Mbar atom-pair terms (Mbar = 116.4 neighbours inside the COM gate), 337 x 6 phase
+        # terms; launches of the move kernel per move; the driver never synchronises a stream
+        mbar = 4.0 / 3.0 * np.pi * RCUT ** 3 * n_mol / box ** 3
+        v = out["value"]
+        out["work_counts"] = {
+            "com_tests_per_s": v * 2 * (n_mol - 1), "atom_pair_terms_per_s": v * 2 * 9 * mbar,
+            "lj_pair_terms_per_s": v * 2 * mbar, "phase_terms_per_s": v * N_K * 6,
+            "move_kernel_launches_per_move": launches / max(st["moves"], 1),
+            "stream_syncs_per_move": 0.0,
+            "pcie_bytes_per_move": {"h2d": 1 if args.device_moves else 200, "d2h": 64}}
         if not args.no_secondary:
             # the same path at BASELINE's two named replica counts, on this rank's GPU:
             # configs[1] = one chain (latency-bound), configs[2] = 256 replicas over 8 GPUs = 32/GPU
@@ -306,9 +306,16 @@ def main():
             out["cpu_baseline"] = {
                 "value": mps, "unit": "moves/s", "cores": 1, "kind": "port",
                 "sample": f"{n} trial moves (2x LJ_poly_dU + 2x EwaldShort + RecipMove) of the "
-                          f"same 750-molecule system in {dt:.1f} s, C oracle, 1 thread",
+                          f"same 750-molecule system in {dt:.1f} s, C oracle (C loop), 1 thread",
                 "ns_per_full_energy_eval": 1e9 * tf,
             }
+            nt = min(len(os.sched_getaffinity(0)), 64)
+            if nt > 1 and args.cpu_seconds >= 2:
+                mps_all, n_all, dt_all, _ = cpu_baseline(a, args.cpu_seconds / 2, nt)
+                out["cpu_baseline_all_cores"] = {
+                    "value": mps_all, "unit": "moves/s", "cores": nt, "kind": "port",
+                    "sample": f"{n_all} trial moves, one independent chain per thread, "
+                              f"{dt_all:.1f} s"}
         print(json.dumps(out))
     b.close()
     if world > 1:

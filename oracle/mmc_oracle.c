@@ -586,3 +586,103 @@ int32_t orc_trial_move(int64_t i, int64_t n_mol, double *com, const int64_t *fir
     memcpy(coords + 3 * (fa - 1), ra_old, sizeof(double) * 3 * na);
     return st;
 }
+
+/* ---- timing helper for bench.py's cpu_baseline (not part of the restatement) ------------------
+ * n_threads independent copies of the system; each thread does Loop()'s hot-path calls
+ * (orc_trial_move: 2x LJ_poly_dU + 2x EwaldShort + RecipMove) for successive molecules with small
+ * rigid translations, rejecting every move (main.jl:628), until `seconds` have passed.  Returns
+ * the total number of trial moves; *elapsed = wall time of the slowest thread. */
+#include <pthread.h>
+#include <stdlib.h>
+#include <time.h>
+
+typedef struct {
+    int64_t n_mol, n_atoms, n_types, nk, k_sq_max, nkvecs, done;
+    const double *com, *coords, *charge, *eps, *sig, *cfac, *sum_old;
+    const int64_t *first_atom, *last_atom, *atype;
+    const int32_t *kxyz;
+    double lj_rcut, qq_rcut, box, kappa, factor, dr_max, seconds, elapsed;
+    uint64_t seed;
+} bench_arg;
+
+static double now_s(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *bench_thread(void *p)
+{
+    bench_arg *a = (bench_arg *)p;
+    double *com = malloc(sizeof(double) * 3 * a->n_mol);
+    double *coords = malloc(sizeof(double) * 3 * a->n_atoms);
+    double *s_new = malloc(sizeof(double) * 2 * a->nkvecs);
+    memcpy(com, a->com, sizeof(double) * 3 * a->n_mol);
+    memcpy(coords, a->coords, sizeof(double) * 3 * a->n_atoms);
+    uint64_t x = a->seed * 0x9e3779b97f4a7c15ULL + 1;
+    const double t0 = now_s();
+    int64_t n = 0;
+    for (;;) {
+        const int64_t i = n % a->n_mol + 1, fa = a->first_atom[i - 1], na = a->last_atom[i - 1] - fa + 1;
+        double cn[3], an[3 * 16], d[4], dv[3];
+        int32_t ov;
+        for (int k = 0; k < 3; k++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17; /* xorshift64 */
+            dv[k] = ((double)(x >> 11) * 0x1.0p-53 - 0.5) * a->dr_max;
+            cn[k] = com[3 * (i - 1) + k] + dv[k];
+        }
+        for (int64_t q = 0; q < na && q < 16; q++)
+            for (int k = 0; k < 3; k++)
+                an[3 * q + k] = coords[3 * (fa - 1 + q) + k] + dv[k];
+        memcpy(s_new, a->sum_old, sizeof(double) * 2 * a->nkvecs);
+        orc_trial_move(i, a->n_mol, com, a->first_atom, a->last_atom, coords, a->atype, a->charge,
+                       a->n_types, a->eps, a->sig, a->lj_rcut, a->qq_rcut, a->box, a->kappa, a->nk,
+                       a->k_sq_max, a->nkvecs, a->kxyz, a->cfac, a->factor, a->sum_old, s_new, cn,
+                       an, d, &ov);
+        n++;
+        if ((n & 15) == 0 && now_s() - t0 > a->seconds)
+            break;
+    }
+    a->elapsed = now_s() - t0;
+    a->done = n;
+    free(com); free(coords); free(s_new);
+    return NULL;
+}
+
+int64_t orc_bench_trial_moves(int64_t n_mol, int64_t n_atoms, const double *com,
+                              const int64_t *first_atom, const int64_t *last_atom,
+                              const double *coords, const int64_t *atype, const double *charge,
+                              int64_t n_types, const double *eps, const double *sig,
+                              double lj_rcut, double qq_rcut, double box, double kappa, int64_t nk,
+                              int64_t k_sq_max, int64_t nkvecs, const int32_t *kxyz,
+                              const double *cfac, double factor, const double *sum_old,
+                              double dr_max, uint64_t seed, int32_t n_threads, double seconds,
+                              double *elapsed)
+{
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 1024) n_threads = 1024;
+    bench_arg *args = calloc((size_t)n_threads, sizeof(bench_arg));
+    pthread_t *th = calloc((size_t)n_threads, sizeof(pthread_t));
+    for (int t = 0; t < n_threads; t++) {
+        bench_arg *a = &args[t];
+        a->n_mol = n_mol; a->n_atoms = n_atoms; a->n_types = n_types; a->nk = nk;
+        a->k_sq_max = k_sq_max; a->nkvecs = nkvecs;
+        a->com = com; a->coords = coords; a->charge = charge; a->eps = eps; a->sig = sig;
+        a->cfac = cfac; a->sum_old = sum_old; a->first_atom = first_atom; a->last_atom = last_atom;
+        a->atype = atype; a->kxyz = kxyz;
+        a->lj_rcut = lj_rcut; a->qq_rcut = qq_rcut; a->box = box; a->kappa = kappa;
+        a->factor = factor; a->dr_max = dr_max; a->seconds = seconds; a->seed = seed + (uint64_t)t;
+        pthread_create(&th[t], NULL, bench_thread, a);
+    }
+    int64_t total = 0;
+    double worst = 0.0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        total += args[t].done;
+        if (args[t].elapsed > worst) worst = args[t].elapsed;
+    }
+    if (elapsed) *elapsed = worst;
+    free(args); free(th);
+    return total;
+}

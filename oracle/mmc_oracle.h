@@ -140,6 +140,20 @@ int32_t orc_trial_move(int64_t i, int64_t n_mol, double *com, const int64_t *fir
                        const double *sum_old, double *sum_new, const double *com_new,
                        const double *atoms_new, double d[4], int32_t *overlap);
 
+/* Timing helper for bench.py's cpu_baseline legs (not part of the restatement): n_threads
+ * independent copies of the system, each running orc_trial_move on successive molecules with
+ * small rigid translations (every move rejected) for `seconds`.  Returns the total number of
+ * trial moves, *elapsed = the slowest thread's wall time. */
+int64_t orc_bench_trial_moves(int64_t n_mol, int64_t n_atoms, const double *com,
+                              const int64_t *first_atom, const int64_t *last_atom,
+                              const double *coords, const int64_t *atype, const double *charge,
+                              int64_t n_types, const double *eps, const double *sig,
+                              double lj_rcut, double qq_rcut, double box, double kappa, int64_t nk,
+                              int64_t k_sq_max, int64_t nkvecs, const int32_t *kxyz,
+                              const double *cfac, double factor, const double *sum_old,
+                              double dr_max, uint64_t seed, int32_t n_threads, double seconds,
+                              double *elapsed);
+
 #ifdef __cplusplus
 }
 #endif

@@ -263,3 +263,20 @@ def trial_move(i, s, ew, lj_rcut, qq_rcut, com_new, atoms_new):
     if st != 0:
         raise AssertionError("RecipMove asserts (n == 3, k_sq_max == 27, nk == 5)")
     return d, bool(ov.value)
+
+
+def bench_trial_moves(s, ew, lj_rcut, qq_rcut, dr_max, seed, n_threads, seconds):
+    """Timing helper (orc_bench_trial_moves): a C loop of trial moves in n_threads independent
+    copies of the system.  Returns (total trial moves, wall seconds of the slowest thread)."""
+    L = lib()
+    L.orc_bench_trial_moves.restype = C.c_int64
+    el = C.c_double()
+    n = L.orc_bench_trial_moves(
+        C.c_int64(s.n_mol), C.c_int64(s.coords.shape[0]), _d(s.com), _i(s.first_atom),
+        _i(s.last_atom), _d(s.coords), _i(s.atype), _d(s.charge), C.c_int64(s.n_types), _d(s.eps),
+        _d(s.sig), C.c_double(lj_rcut), C.c_double(qq_rcut), C.c_double(s.box),
+        C.c_double(ew.kappa), C.c_int64(ew.nk), C.c_int64(ew.k_sq_max), C.c_int64(ew.NKVECS),
+        ew.kxyz.ctypes.data_as(_i32p), _d(ew.cfac), C.c_double(ew.factor), _cview(ew.sumQExpOld),
+        C.c_double(dr_max), C.c_uint64(seed), C.c_int32(n_threads), C.c_double(seconds),
+        C.byref(el))
+    return int(n), float(el.value)
