@@ -66,13 +66,33 @@ struct PairAcc {
 // Ewald/ewalds.jl:30-38 (== boundaries.jl:8-14): minimum image by comparison, not by rounding.
 // Branch-free but bit-identical to the reference's two-branch form:
 //   c1 <  c2 (d > 0):  (c2-c1) < (c1-c2+box) ? d : d - box      c1-c2 == -d exactly, so the test is
-//   c1 >= c2 (d <= 0): (c1-c2) < (c2-c1+box) ? d : d + box      |d| < box - |d| in both branches
-// and the wrapped value is d - copysign(box, d) (IEEE: d - (-box) == d + box).  7 VALU instead of 12.
-__device__ __forceinline__ double vector1D(double c1, double c2, double box)
+//   c1 >= c2 (d <= 0): (c1-c2) < (c2-c1+box) ? d : d + box      |d| < fl(box - |d|) in both branches.
+// * The test equals |d| < box/2 EXACTLY: box/2 is representable and rounding is monotone, so
+//   |d| < box/2 => fl(box-|d|) >= box/2 > |d|, |d| > box/2 => fl(box-|d|) <= box/2 < |d|, and at
+//   |d| == box/2 both are false.
+// * The wrapped value d -+ box is fma(m, -box, d) with m = 0 or +-1 (m*box exact, one rounding,
+//   and d + 0*(-box) == d): no 64-bit select.  5 VALU (sub, cmp, bfi, cndmask, fma) instead of 12.
+struct BoxConsts {
+    double half, neg; // box/2 and -box, kept in registers across the pair loops
+};
+__device__ __forceinline__ BoxConsts box_consts(double box)
+{
+    BoxConsts b;
+    b.half = 0.5 * box;
+    b.neg = -box;
+    return b;
+}
+__device__ __forceinline__ double vector1D(double c1, double c2, const BoxConsts &bc)
 {
     const double d = c2 - c1;
-    const double ad = fabs(d);
-    return (ad < (box - ad)) ? d : d - copysign(box, d);
+    // m = 0 or copysign(1, d): one v_bfi_b32 and one v_cndmask_b32 on the high dword (the low
+    // dwords of 0.0 and 1.0 are both zero)
+    const double m = (fabs(d) < bc.half) ? 0.0 : copysign(1.0, d);
+    return fma(m, bc.neg, d);
+}
+__device__ __forceinline__ double vector1D(double c1, double c2, double box)
+{
+    return vector1D(c1, c2, box_consts(box));
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }

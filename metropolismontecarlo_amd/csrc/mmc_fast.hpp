@@ -78,6 +78,23 @@ __device__ __forceinline__ double qq_table_eval(const double *tab, double u)
     return acc;
 }
 
+// The same with the piece index clamped into the table: for predicated callers that evaluate
+// every lane and discard what lies outside [UMIN, UMAX) afterwards.
+__device__ __forceinline__ double qq_table_eval_clamped(const double *tab, double u)
+{
+    const long long bits = __double_as_longlong(u);
+    const int idx = min(max((int)(bits >> 48) - 0x3FD0, 0), MMC_QQ_NINT - 1);
+    const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
+    const double d = __longlong_as_double(lo | 0x3FF0000000000000LL);
+    const double t = 2.0 * d - 3.0;
+    const double *c = tab + idx * MMC_QQ_NCOEF;
+    double acc = c[MMC_QQ_DEG];
+#pragma unroll
+    for (int j = MMC_QQ_DEG - 1; j >= 0; j--)
+        acc = fma(acc, t, c[j]);
+    return acc;
+}
+
 // u < UMIN happens only for like charges closer than 0.5 A (opposite charges that close are
 // overlaps).  There x = kappa*r <= 0.25 and the Maclaurin series of erf needs 9 terms for 1e-16:
 // erfc(x)/r = 1/r - (2 kappa/sqrt(pi)) * sum_n (-1)^n x^(2n) / (n! (2n+1)).
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
     const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0; // >= j_begin
     const int w = wave_id();
+    const BoxConsts bc = box_consts(box);
 
     // ================= trip 1: everything that depends on nothing =================
     if (tid < MV_WORDS)
@@ -380,28 +398,46 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
                 }
                 __syncthreads();
                 // ---- Coulomb pass: one lane per (neighbour, a, b), both states ----
-                for (int g = tid; g < nt * 9; g += MMC_BLOCK) {
-                    const int n = g / 9, ab = g - n * 9;
-                    const int a = ab / 3, b = ab - 3 * a;
-                    const int f = sm.tflag[n];
-                    const double bx = sm.tile[n * MMC_REC + 3 * b],
-                                 by = sm.tile[n * MMC_REC + 3 * b + 1],
-                                 bz = sm.tile[n * MMC_REC + 3 * b + 2];
-                    const double qq = sm.qq9[ab];
+                // Straight-line and predicated: the two states' chains (minimum image -> r^2 ->
+                // table piece -> Horner) are independent, so written without divergent regions
+                // they interleave and hide each other's LDS / fp64 latency.  A term that the
+                // reference skips is added as +0.0, which leaves the sum bit-identical.
+                {
+                    int n = tid / 9, ab = tid - 9 * n; // g = 9 n + ab; g += 256 = 9*28 + 4
+                    for (int g = tid; g < nt * 9; g += MMC_BLOCK) {
+                        const int a = (ab * 11) >> 5, b = ab - 3 * a; // ab / 3, ab % 3 for ab < 9
+                        const int f = sm.tflag[n];
+                        const double bx = sm.tile[n * MMC_REC + 3 * b],
+                                     by = sm.tile[n * MMC_REC + 3 * b + 1],
+                                     bz = sm.tile[n * MMC_REC + 3 * b + 2];
+                        const double qq = sm.qq9[ab];
+                        double u[2];
 #pragma unroll
-                    for (int st = 0; st < 2; st++) {
-                        if (f & (4 << st)) {
-                            const double rx = vector1D(ch_at(st, a, 0), bx, box);
-                            const double ry = vector1D(ch_at(st, a, 1), by, box);
-                            const double rz = vector1D(ch_at(st, a, 2), bz, box);
-                            const double rab2 = rx * rx + ry * ry + rz * rz;
-                            if ((rab2 < pp.ovr) && (qq < 0)) {          // ewalds.jl:359
-                                if (st == 0) ovl0 = 1; else ovl1 = 1;
-                            } else if (rab2 < pp.qq_slack_sq) {          // ewalds.jl:362
-                                const double e = qq * qq_pair(sm.qtab, rab2, pp.kappa);
-                                if (st == 0) a_q0 += e; else a_q1 += e;
-                            }
+                        for (int st = 0; st < 2; st++) {
+                            const double rx = vector1D(ch_at(st, a, 0), bx, bc);
+                            const double ry = vector1D(ch_at(st, a, 1), by, bc);
+                            const double rz = vector1D(ch_at(st, a, 2), bz, bc);
+                            u[st] = rx * rx + ry * ry + rz * rz;
                         }
+                        const bool g0 = (f & 4) != 0, g1 = (f & 8) != 0; // ewalds.jl:340 per state
+                        const bool ov0 = g0 && (u[0] < pp.ovr) && (qq < 0); // ewalds.jl:359
+                        const bool ov1 = g1 && (u[1] < pp.ovr) && (qq < 0);
+                        const bool in0 = g0 && !ov0 && (u[0] < pp.qq_slack_sq); // ewalds.jl:362
+                        const bool in1 = g1 && !ov1 && (u[1] < pp.qq_slack_sq);
+                        double e0 = qq_table_eval_clamped(sm.qtab, u[0]);
+                        double e1 = qq_table_eval_clamped(sm.qtab, u[1]);
+                        // like charges closer than 0.5 A: the series (practically never taken)
+                        if (__any((in0 && u[0] < MMC_QQ_UMIN) || (in1 && u[1] < MMC_QQ_UMIN))) {
+                            if (u[0] < MMC_QQ_UMIN) e0 = qq_pair(sm.qtab, u[0], pp.kappa);
+                            if (u[1] < MMC_QQ_UMIN) e1 = qq_pair(sm.qtab, u[1], pp.kappa);
+                        }
+                        a_q0 += in0 ? qq * e0 : 0.0;
+                        a_q1 += in1 ? qq * e1 : 0.0;
+                        ovl0 |= ov0 ? 1 : 0;
+                        ovl1 |= ov1 ? 1 : 0;
+                        n += 28;
+                        ab += 4;
+                        if (ab >= 9) { ab -= 9; n += 1; }
                     }
                 }
                 // ---- LJ pass: only atom pairs with eps > 0.001 ----
