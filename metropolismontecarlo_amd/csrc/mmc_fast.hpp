@@ -321,191 +321,248 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
         }
     }
 
-    if (do_pairs) {
-        const int n_ljp = fc.n_ljp;
-        for (int jb = j_begin; jb < j_end; jb += MMC_FLIST_CAP) {
-            const int je = min(jb + MMC_FLIST_CAP, j_end);
-            const int len = je - jb;
-            const int seg = ((len + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64;
-            const int wj0 = jb + w * seg, wj1 = min(wj0 + seg, je);
-            // ---- phase A: COM gates of both states, compact survivors (ascending j) ----
-            int count = 0;
-            auto gate_and_append = [&](int j, double cx, double cy, double cz) {
-                int f = 0;
-                if (j < wj1 && j != i0) {
-                    if (j == pend) { cx = pd_word(9); cy = pd_word(10); cz = pd_word(11); }
-#pragma unroll
-                    for (int st = 0; st < 2; st++) {
-                        const double dx = vector1D(ch_com(st, 0), cx, box);
-                        const double dy = vector1D(ch_com(st, 1), cy, box);
-                        const double dz = vector1D(ch_com(st, 2), cz, box);
-                        const double r2 = dx * dx + dy * dy + dz * dz;
-                        f |= (r2 < pp.lj_gate_sq) ? (1 << st) : 0;       // energy.jl:254
-                        f |= (r2 < pp.qq_gate_sq) ? (4 << st) : 0;       // ewalds.jl:340
-                    }
-                }
-                const unsigned long long m = __ballot(f != 0);
-                if (f)
-                    sm.list[w * seg + count + lanes_below(m)] = j | (f << 27);
-                count += __popcll(m);
-            };
-            int base = wj0;
-            if (jb == j_begin) { // the prefetched iterations
-#pragma unroll
-                for (int it = 0; it < MMC_PRE; it++) {
-                    if (base < wj1) {
-                        gate_and_append(base + lane_id(), pcx[it], pcy[it], pcz[it]);
-                        base += 64;
-                    }
-                }
-            }
-            for (; base < wj1; base += 64) { // larger systems: plain loads
-                const int j = base + lane_id();
-                double cx = 0.0, cy = 0.0, cz = 0.0;
-                if (j < wj1) { cx = comx[j]; cy = comy[j]; cz = comz[j]; }
-                gate_and_append(j, cx, cy, cz);
-            }
-            if (lane_id() == 0)
-                sm.wcnt[w] = count;
-            __syncthreads();
-            const int c0 = sm.wcnt[0], c1 = sm.wcnt[1], c2 = sm.wcnt[2], c3 = sm.wcnt[3];
-            const int total = c0 + c1 + c2 + c3;
+    const int n_ljp = fc.n_ljp;
+    // State of the current chunk of the molecule range (chunks of MMC_FLIST_CAP molecules; one
+    // chunk at 750 molecules): list segment size and the four waves' survivor counts.
+    int seg = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0, total = 0;
 
-            for (int t0 = 0; t0 < total; t0 += MMC_TILE) {
-                const int nt = min(MMC_TILE, total - t0);
-                // ---- trip 2: gather 6 lanes x 16 B per neighbour record -> LDS tile ----
-                for (int g = tid; g < nt * 6; g += MMC_BLOCK) {
-                    const int n = g / 6, piece = g - n * 6;
-                    const int pos = t0 + n;
-                    int slot;
-                    if (pos < c0) slot = pos;
-                    else if (pos < c0 + c1) slot = seg + (pos - c0);
-                    else if (pos < c0 + c1 + c2) slot = 2 * seg + (pos - c0 - c1);
-                    else slot = 3 * seg + (pos - c0 - c1 - c2);
-                    const int ent = sm.list[slot];
-                    const int j = ent & ((1 << 27) - 1);
-                    double2 v;
-                    if (j == pend) {
-                        v.x = pd_word(2 * piece);
-                        v.y = pd_word(2 * piece + 1);
-                    } else {
-                        v = *reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC +
-                                                               2 * piece);
-                    }
-                    *reinterpret_cast<double2 *>(&sm.tile[n * MMC_REC + 2 * piece]) = v;
-                    if (piece == 0)
-                        sm.tflag[n] = ent >> 27;
-                }
-                __syncthreads();
-                // ---- Coulomb pass: one lane per (neighbour, a, b), both states ----
-                // Straight-line and predicated: the two states' chains (minimum image -> r^2 ->
-                // table piece -> Horner) are independent, so written without divergent regions
-                // they interleave and hide each other's LDS / fp64 latency.  A term that the
-                // reference skips is added as +0.0, which leaves the sum bit-identical.
-                {
-                    int n = tid / 9, ab = tid - 9 * n; // g = 9 n + ab; g += 256 = 9*28 + 4
-                    for (int g = tid; g < nt * 9; g += MMC_BLOCK) {
-                        const int a = (ab * 11) >> 5, b = ab - 3 * a; // ab / 3, ab % 3 for ab < 9
-                        const int f = sm.tflag[n];
-                        const double bx = sm.tile[n * MMC_REC + 3 * b],
-                                     by = sm.tile[n * MMC_REC + 3 * b + 1],
-                                     bz = sm.tile[n * MMC_REC + 3 * b + 2];
-                        const double qq = sm.qq9[ab];
-                        double u[2];
+    // ---- phase A: COM gates of both states, survivors compacted into sm.list (ascending j) ----
+    auto scan_chunk = [&](int jb, bool prefetched) {
+        const int je = min(jb + MMC_FLIST_CAP, j_end);
+        const int len = max(je - jb, 0);
+        seg = ((len + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64;
+        const int wj0 = jb + w * seg, wj1 = min(wj0 + seg, je);
+        int count = 0;
+        auto gate_and_append = [&](int j, double cx, double cy, double cz) {
+            int f = 0;
+            if (j < wj1 && j != i0) {
+                if (j == pend) { cx = pd_word(9); cy = pd_word(10); cz = pd_word(11); }
 #pragma unroll
-                        for (int st = 0; st < 2; st++) {
-                            const double rx = vector1D(ch_at(st, a, 0), bx, bc);
-                            const double ry = vector1D(ch_at(st, a, 1), by, bc);
-                            const double rz = vector1D(ch_at(st, a, 2), bz, bc);
-                            u[st] = rx * rx + ry * ry + rz * rz;
-                        }
-                        const bool g0 = (f & 4) != 0, g1 = (f & 8) != 0; // ewalds.jl:340 per state
-                        const bool ov0 = g0 && (u[0] < pp.ovr) && (qq < 0); // ewalds.jl:359
-                        const bool ov1 = g1 && (u[1] < pp.ovr) && (qq < 0);
-                        const bool in0 = g0 && !ov0 && (u[0] < pp.qq_slack_sq); // ewalds.jl:362
-                        const bool in1 = g1 && !ov1 && (u[1] < pp.qq_slack_sq);
-                        double e0 = qq_table_eval_clamped(sm.qtab, u[0]);
-                        double e1 = qq_table_eval_clamped(sm.qtab, u[1]);
-                        // like charges closer than 0.5 A: the series (practically never taken)
-                        if (__any((in0 && u[0] < MMC_QQ_UMIN) || (in1 && u[1] < MMC_QQ_UMIN))) {
-                            if (u[0] < MMC_QQ_UMIN) e0 = qq_pair(sm.qtab, u[0], pp.kappa);
-                            if (u[1] < MMC_QQ_UMIN) e1 = qq_pair(sm.qtab, u[1], pp.kappa);
-                        }
-                        a_q0 += in0 ? qq * e0 : 0.0;
-                        a_q1 += in1 ? qq * e1 : 0.0;
-                        ovl0 |= ov0 ? 1 : 0;
-                        ovl1 |= ov1 ? 1 : 0;
-                        n += 28;
-                        ab += 4;
-                        if (ab >= 9) { ab -= 9; n += 1; }
-                    }
+                for (int st = 0; st < 2; st++) {
+                    const double dx = vector1D(ch_com(st, 0), cx, bc);
+                    const double dy = vector1D(ch_com(st, 1), cy, bc);
+                    const double dz = vector1D(ch_com(st, 2), cz, bc);
+                    const double r2 = dx * dx + dy * dy + dz * dz;
+                    f |= (r2 < pp.lj_gate_sq) ? (1 << st) : 0;       // energy.jl:254
+                    f |= (r2 < pp.qq_gate_sq) ? (4 << st) : 0;       // ewalds.jl:340
                 }
-                // ---- LJ pass: only atom pairs with eps > 0.001 ----
-                for (int g = tid; g < nt * n_ljp; g += MMC_BLOCK) {
-                    int n = g, p = 0;
-                    if (n_ljp != 1) { // water has one LJ pair (O-O): skip the integer division
-                        n = g / n_ljp;
-                        p = g - n * n_ljp;
-                    }
-                    const int ab = sm.ljp_ab[p];
-                    const int a = ab / 3, b = ab - 3 * a;
-                    const int f = sm.tflag[n];
-                    const double e = sm.ljp_eps[p], sg = sm.ljp_sig[p];
-                    const double *t = &sm.tile[n * MMC_REC];
+            }
+            const unsigned long long m = __ballot(f != 0);
+            if (f)
+                sm.list[w * seg + count + lanes_below(m)] = j | (f << 27);
+            count += __popcll(m);
+        };
+        int base = wj0;
+        if (prefetched) { // the iterations whose loads were issued at kernel entry
 #pragma unroll
-                    for (int st = 0; st < 2; st++) {
-                        if (f & (1 << st)) {
-                            const double rx = vector1D(ch_at(st, a, 0), t[3 * b], box);
-                            const double ry = vector1D(ch_at(st, a, 1), t[3 * b + 1], box);
-                            const double rz = vector1D(ch_at(st, a, 2), t[3 * b + 2], box);
-                            const double rab2 = rx * rx + ry * ry + rz * rz;
-                            if (rab2 < pp.lj_slack_sq) {                 // energy.jl:270
-                                const double cx = vector1D(ch_com(st, 0), t[9], box);
-                                const double cy = vector1D(ch_com(st, 1), t[10], box);
-                                const double cz = vector1D(ch_com(st, 2), t[11], box);
-                                const double s2 = sg * sg / rab2;
-                                const double s6 = s2 * s2 * s2;
-                                const double s12 = s6 * s6;
-                                const double virab = e * (2.0 * s12 - s6);
-                                const double f0 = rx * virab * s2, f1 = ry * virab * s2,
-                                             f2 = rz * virab * s2;
-                                const double pe = e * (s12 - s6);
-                                const double pv = cx * f0 + cy * f1 + cz * f2;
-                                if (st == 0) { a_lj0 += pe; a_v0 += pv; }
-                                else { a_lj1 += pe; a_v1 += pv; }
-                            }
-                        }
-                    }
+            for (int it = 0; it < MMC_PRE; it++) {
+                if (base < wj1) {
+                    gate_and_append(base + lane_id(), pcx[it], pcy[it], pcz[it]);
+                    base += 64;
                 }
-                __syncthreads(); // the tile and the list are reused
             }
         }
-    }
-    // ---- reciprocal part for this thread's k-vectors (ewalds.jl:803-821) ----
-    if (do_recip) {
-        __syncthreads(); // ptab (a no-op cost-wise when the pair loops already synchronised)
-        double *Sn = s_buf(bv, r, scur ^ 1);
-#pragma unroll 1
-        for (int h = 0; h < 2; h++) {
-            const int k = tid + h * MMC_BLOCK;
-            if (k < bv.nkvecs) {
-                const int kp = h ? kp1 : kp0;
-                const double cf = h ? cf1 : cf0;
-                const double orr = h ? so1r : so0r, oi = h ? so1i : so0i;
-                const int kx = kp & 15, ky = (kp >> 4) & 15, kz = (kp >> 8) & 15;
-                double nr = orr, ni = oi;
-#pragma unroll 1
-                for (int l = 0; l < 3; l++) {
-                    const cplx tn = c_mul(c_mul(sm.ptab[1][l][0][5 + kx], sm.ptab[1][l][1][ky]),
-                                          sm.ptab[1][l][2][kz]);
-                    const cplx to = c_mul(c_mul(sm.ptab[0][l][0][5 + kx], sm.ptab[0][l][1][ky]),
-                                          sm.ptab[0][l][2][kz]);
-                    nr += fc.q[l] * (tn.re - to.re);
-                    ni += fc.q[l] * (tn.im - to.im);
+        for (; base < wj1; base += 64) { // larger systems: plain loads
+            const int j = base + lane_id();
+            double cx = 0.0, cy = 0.0, cz = 0.0;
+            if (j < wj1) { cx = comx[j]; cy = comy[j]; cz = comz[j]; }
+            gate_and_append(j, cx, cy, cz);
+        }
+        if (lane_id() == 0)
+            sm.wcnt[w] = count;
+        __syncthreads();
+        c0 = sm.wcnt[0]; c1 = sm.wcnt[1]; c2 = sm.wcnt[2]; c3 = sm.wcnt[3];
+        total = c0 + c1 + c2 + c3;
+    };
+
+    // ---- trip 2: one 16-byte piece (of 6) of the record of the neighbour at list position t0 + n
+    auto gather_piece = [&](int t0, int g, int &ent) {
+        const int n = g / 6, piece = g - n * 6;
+        const int pos = t0 + n;
+        int slot;
+        if (pos < c0) slot = pos;
+        else if (pos < c0 + c1) slot = seg + (pos - c0);
+        else if (pos < c0 + c1 + c2) slot = 2 * seg + (pos - c0 - c1);
+        else slot = 3 * seg + (pos - c0 - c1 - c2);
+        ent = sm.list[slot];
+        const int j = ent & ((1 << 27) - 1);
+        double2 v;
+        if (j == pend) {
+            v.x = pd_word(2 * piece);
+            v.y = pd_word(2 * piece + 1);
+        } else {
+            v = *reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC + 2 * piece);
+        }
+        return v;
+    };
+    auto store_piece = [&](int g, double2 v, int ent) {
+        const int n = g / 6, piece = g - n * 6;
+        *reinterpret_cast<double2 *>(&sm.tile[n * MMC_REC + 2 * piece]) = v;
+        if (piece == 0)
+            sm.tflag[n] = ent >> 27;
+    };
+
+    // ---- the pair passes over the nt neighbours staged in sm.tile ----
+    auto pair_passes = [&](int nt) {
+        // Coulomb pass: one lane per (neighbour, a, b), both states.  Straight-line and
+        // predicated: the two states' chains (minimum image -> r^2 -> table piece -> Horner) are
+        // independent, so written without divergent regions they interleave and hide each
+        // other's LDS / fp64 latency.  A term that the reference skips is added as +0.0, which
+        // leaves the sum bit-identical.
+        {
+            int n = tid / 9, ab = tid - 9 * n; // g = 9 n + ab; g += 256 = 9*28 + 4
+            for (int g = tid; g < nt * 9; g += MMC_BLOCK) {
+                const int a = (ab * 11) >> 5, b = ab - 3 * a; // ab / 3, ab % 3 for ab < 9
+                const int f = sm.tflag[n];
+                const double bx = sm.tile[n * MMC_REC + 3 * b],
+                             by = sm.tile[n * MMC_REC + 3 * b + 1],
+                             bz = sm.tile[n * MMC_REC + 3 * b + 2];
+                const double qq = sm.qq9[ab];
+                double u[2];
+#pragma unroll
+                for (int st = 0; st < 2; st++) {
+                    const double rx = vector1D(ch_at(st, a, 0), bx, bc);
+                    const double ry = vector1D(ch_at(st, a, 1), by, bc);
+                    const double rz = vector1D(ch_at(st, a, 2), bz, bc);
+                    u[st] = rx * rx + ry * ry + rz * rz;
                 }
-                Sn[2 * k] = nr; Sn[2 * k + 1] = ni;
-                a_rec += cf * ((nr * nr - (-ni) * ni) - (orr * orr - (-oi) * oi));
+                const bool g0 = (f & 4) != 0, g1 = (f & 8) != 0; // ewalds.jl:340 per state
+                const bool ov0 = g0 && (u[0] < pp.ovr) && (qq < 0); // ewalds.jl:359
+                const bool ov1 = g1 && (u[1] < pp.ovr) && (qq < 0);
+                const bool in0 = g0 && !ov0 && (u[0] < pp.qq_slack_sq); // ewalds.jl:362
+                const bool in1 = g1 && !ov1 && (u[1] < pp.qq_slack_sq);
+                double e0 = qq_table_eval_clamped(sm.qtab, u[0]);
+                double e1 = qq_table_eval_clamped(sm.qtab, u[1]);
+                // like charges closer than 0.5 A: the series (practically never taken)
+                if (__any((in0 && u[0] < MMC_QQ_UMIN) || (in1 && u[1] < MMC_QQ_UMIN))) {
+                    if (u[0] < MMC_QQ_UMIN) e0 = qq_pair(sm.qtab, u[0], pp.kappa);
+                    if (u[1] < MMC_QQ_UMIN) e1 = qq_pair(sm.qtab, u[1], pp.kappa);
+                }
+                a_q0 += in0 ? qq * e0 : 0.0;
+                a_q1 += in1 ? qq * e1 : 0.0;
+                ovl0 |= ov0 ? 1 : 0;
+                ovl1 |= ov1 ? 1 : 0;
+                n += 28;
+                ab += 4;
+                if (ab >= 9) { ab -= 9; n += 1; }
             }
+        }
+        // LJ pass: only atom pairs with eps > 0.001
+        for (int g = tid; g < nt * n_ljp; g += MMC_BLOCK) {
+            int n = g, p = 0;
+            if (n_ljp != 1) { // water has one LJ pair (O-O): skip the integer division
+                n = g / n_ljp;
+                p = g - n * n_ljp;
+            }
+            const int ab = sm.ljp_ab[p];
+            const int a = ab / 3, b = ab - 3 * a;
+            const int f = sm.tflag[n];
+            const double e = sm.ljp_eps[p], sg = sm.ljp_sig[p];
+            const double *t = &sm.tile[n * MMC_REC];
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                if (f & (1 << st)) {
+                    const double rx = vector1D(ch_at(st, a, 0), t[3 * b], bc);
+                    const double ry = vector1D(ch_at(st, a, 1), t[3 * b + 1], bc);
+                    const double rz = vector1D(ch_at(st, a, 2), t[3 * b + 2], bc);
+                    const double rab2 = rx * rx + ry * ry + rz * rz;
+                    if (rab2 < pp.lj_slack_sq) {                 // energy.jl:270
+                        const double cx = vector1D(ch_com(st, 0), t[9], bc);
+                        const double cy = vector1D(ch_com(st, 1), t[10], bc);
+                        const double cz = vector1D(ch_com(st, 2), t[11], bc);
+                        const double s2 = sg * sg / rab2;
+                        const double s6 = s2 * s2 * s2;
+                        const double s12 = s6 * s6;
+                        const double virab = e * (2.0 * s12 - s6);
+                        const double f0 = rx * virab * s2, f1 = ry * virab * s2,
+                                     f2 = rz * virab * s2;
+                        const double pe = e * (s12 - s6);
+                        const double pv = cx * f0 + cy * f1 + cz * f2;
+                        if (st == 0) { a_lj0 += pe; a_v0 += pv; }
+                        else { a_lj1 += pe; a_v1 += pv; }
+                    }
+                }
+            }
+        }
+    };
+
+    // ===== chunk 0: scan, REQUEST the first neighbour tile into registers, do the reciprocal part
+    // while that round trip is in flight, then stage the tile and run the pair passes =====
+    scan_chunk(j_begin, true);
+    {
+        double2 greg[MMC_GATHER_REGS];
+        int gent[MMC_GATHER_REGS];
+        const int nt0 = min(MMC_TILE, total);
+#pragma unroll
+        for (int q = 0; q < MMC_GATHER_REGS; q++) {
+            const int g = tid + q * MMC_BLOCK;
+            gent[q] = 0;
+            greg[q] = make_double2(0.0, 0.0);
+            if (g < nt0 * 6)
+                greg[q] = gather_piece(0, g, gent[q]);
+        }
+        // ---- reciprocal part for this thread's k-vectors (ewalds.jl:803-821) ----
+        if (do_recip) {
+            __syncthreads(); // ptab
+            double *Sn = s_buf(bv, r, scur ^ 1);
+#pragma unroll 1
+            for (int h = 0; h < 2; h++) {
+                const int k = tid + h * MMC_BLOCK;
+                if (k < bv.nkvecs) {
+                    const int kp = h ? kp1 : kp0;
+                    const double cf = h ? cf1 : cf0;
+                    const double orr = h ? so1r : so0r, oi = h ? so1i : so0i;
+                    const int kx = kp & 15, ky = (kp >> 4) & 15, kz = (kp >> 8) & 15;
+                    double nr = orr, ni = oi;
+#pragma unroll 1
+                    for (int l = 0; l < 3; l++) {
+                        const cplx tn = c_mul(c_mul(sm.ptab[1][l][0][5 + kx], sm.ptab[1][l][1][ky]),
+                                              sm.ptab[1][l][2][kz]);
+                        const cplx to = c_mul(c_mul(sm.ptab[0][l][0][5 + kx], sm.ptab[0][l][1][ky]),
+                                              sm.ptab[0][l][2][kz]);
+                        nr += fc.q[l] * (tn.re - to.re);
+                        ni += fc.q[l] * (tn.im - to.im);
+                    }
+                    Sn[2 * k] = nr; Sn[2 * k + 1] = ni;
+                    a_rec += cf * ((nr * nr - (-ni) * ni) - (orr * orr - (-oi) * oi));
+                }
+            }
+        }
+        if (nt0 > 0) {
+#pragma unroll
+            for (int q = 0; q < MMC_GATHER_REGS; q++) {
+                const int g = tid + q * MMC_BLOCK;
+                if (g < nt0 * 6)
+                    store_piece(g, greg[q], gent[q]);
+            }
+            __syncthreads();
+            pair_passes(nt0);
+            __syncthreads(); // the tile and the list are reused
+        }
+    }
+    // ===== everything beyond the first tile: only systems with more than MMC_TILE neighbours
+    // inside the gate or more than MMC_FLIST_CAP molecules per part get here =====
+    {
+        int jb = j_begin, t0 = MMC_TILE;
+        for (;;) {
+            if (t0 >= total) {
+                jb += MMC_FLIST_CAP;
+                if (jb >= j_end)
+                    break;
+                scan_chunk(jb, false);
+                t0 = 0;
+                continue;
+            }
+            const int nt = min(MMC_TILE, total - t0);
+            for (int g = tid; g < nt * 6; g += MMC_BLOCK) {
+                int ent;
+                const double2 v = gather_piece(t0, g, ent);
+                store_piece(g, v, ent);
+            }
+            __syncthreads();
+            pair_passes(nt);
+            __syncthreads();
+            t0 += MMC_TILE;
         }
     }
 
