@@ -40,8 +40,8 @@
 #define MMC_QQ_XMAX 4.0      // kappa * sqrt(r_cut^2 + 100) <= XMAX (degree 10 is enough there)
 #define MMC_QQ_KAPPA_MAX 0.5 // and kappa <= this (the series below UMIN needs kappa*r <= 0.25)
 #define MMC_FLIST_CAP 768
-#define MMC_PRE 2            // COM-scan iterations whose loads are issued at kernel entry
-                             // (3 would cost 10 more VGPRs and the 4th wave per SIMD)
+#define MMC_PRE 3            // COM-scan iterations whose loads are issued at kernel entry: all of
+                             // the scan at 750 molecules (3 x 256), so no second dependent trip
 #define MMC_GATHER_REGS ((MMC_TILE * 6 + MMC_BLOCK - 1) / MMC_BLOCK)
 
 // word offsets (8 B) inside a MoveRec
