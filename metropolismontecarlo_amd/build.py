@@ -20,7 +20,7 @@ ARCH = "gfx950"
 
 SOURCES = ["mmc_hip.hip"]
 DEPS = ["mmc_hip.hip", "mmc_host.hpp", "mmc_device.hpp", "mmc_kernels.hpp", "mmc_fast.hpp", "mmc_total.hpp",
-        "mmc_system.inc",
+        "mmc_propose.hpp", "mmc_study.hpp", "mmc_system.inc",
         "mmc_ctx.inc", "mmc_batch.inc", "mmc_engine.inc"]
 
 

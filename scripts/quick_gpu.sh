@@ -10,3 +10,4 @@ run() { # label, args
 }
 run "default" ""
 run "R=16384" "--replicas 16384"
+run "R=2048" "--replicas 2048"
