@@ -234,6 +234,17 @@ def main():
             "ns_per_full_energy_eval": 1e9 * t_full_max / R,
             "full_energy_evals_per_s": R * world / t_full_max,
         }
+        # M2: a full evaluation is fp64-VALU work, 3.5e7 flop by the survey's
+        # counting (half-pair COM tests, 9 x 48-flop atom-pair terms, 16-flop phase terms) against
+        # 111 KB of compulsory bytes -> quote the fraction of the 78.6 TFLOP/s fp64 vector peak
+        flops_full = (12 * n_mol * (n_mol - 1) / 2 + (9 * 48 + 12) * n_mol
+                      * (4.0 / 3.0 * np.pi * RCUT ** 3 * n_mol / box ** 3) / 2
+                      + 16 * N_K * 3 * n_mol + 120 * 3 * n_mol)
+        out["full_energy_eval"] = {
+            "ns": 1e9 * t_full_max / R, "batched_over_replicas": R,
+            "algorithmic_flops": flops_full, "algorithmic_bytes": algorithmic_bytes_full_eval(n_mol),
+            "achieved_tflops_per_gpu": flops_full * R / t_full_max / 1e12,
+            "frac_fp64_vector_peak_78.6": flops_full * R / t_full_max / 78.6e12}
         if ev and st["timed_launches"]:
             # rank 0's average launch duration over the launches that carried events
             t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
