@@ -82,3 +82,28 @@ def test_philox4x32_known_answers():
     assert ph([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert ph([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def test_branch_free_minimum_image_equals_reference_form_bitwise():
+    """csrc/mmc_device.hpp vector1D: the reference's test `d < L - d` (ewalds.jl:30-38) is taken as
+    |d| < L/2 and the wrapped value as d -+ L in one rounding.  Restated in numpy and compared
+    bit for bit with the oracle's literal two-branch form, including ties at L/2, zero distance,
+    images more than one box away and values one ulp either side of L/2."""
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    cases = []
+    for box in (20.0, 30.0, 53.257, 67.09912345678, 1.0, 1000.0):
+        c1 = rng.random(4000) * box
+        c2 = rng.random(4000) * box
+        cases += [(a, b, box) for a, b in zip(c1, c2)]
+        h = box / 2
+        for d in (h, np.nextafter(h, 0), np.nextafter(h, box), 0.0, box, 1.2 * box, 1.4999 * box):
+            cases += [(0.0, d, box), (d, 0.0, box), (1.0, 1.0 + d, box), (1.0 + d, 1.0, box)]
+    for c1, c2, box in cases:
+        d = c2 - c1
+        m = 0.0 if abs(d) < 0.5 * box else np.copysign(1.0, d)
+        mine = d - box if m > 0 else d + box if m < 0 else d      # fma(m, -box, d), m in {0, +-1}
+        ref = orc.vector1D(c1, c2, box)
+        # the sign of a zero result is irrelevant (it is squared); everything else bit-identical
+        assert mine == ref and (mine != 0.0 or ref == 0.0), (c1, c2, box, mine, ref)
+        assert np.float64(mine).tobytes() == np.float64(ref).tobytes() or mine == 0.0
