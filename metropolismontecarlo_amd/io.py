@@ -5,6 +5,8 @@ Only what the parity fixtures and the bench need: the NIST SPC/E sample-configur
 (Ewald/main.jl:231-275).  Loaders are outside the hot path; they run on
 the host with numpy.
 """
+import os
+
 import numpy as np
 
 from .structs import Tables
@@ -138,3 +140,164 @@ def cubic_lattice_water(n_mol, rho, geometry="spce", seed=11234):
     R[:, 2, 0] = 2 * (x * z - w * y); R[:, 2, 1] = 2 * (y * z + w * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
     coords = com[:, None, :] + np.einsum("mij,aj->mai", R, body)
     return box, com, coords.reshape(-1, 3)
+
+
+# ---- GROMACS-style input decks of the reference ---------------------------
+R_GAS = 0.0083144621   # kJ/(mol K); Ewald/constants.jl -- vdwTable.eps /= R  (main.jl:185)
+
+
+def ReadPDB(pdb_name):
+    """Ewald/setup.jl:30-87.  The reference's fixed columns (1-based 31:38, 40:46, 48:55 for x, y,
+    z; 12:15 atom name; 17:21 residue name; 22:27 residue number; 77:78 element), CRYST1 box.
+    Returns a dict with the fields of the reference's `Topology` struct."""
+    box = np.zeros(3)
+    coords, atomnm, resnm, resnr, elem = [], [], [], [], []
+    with open(pdb_name) as fh:
+        for line in fh:
+            line = line.rstrip("\n")
+            if "ATOM" in line or "HETATM" in line:
+                coords.append([float(line[30:38]), float(line[39:46]), float(line[47:55])])
+                atomnm.append(line[11:15].strip())
+                resnm.append(line[16:21].strip())
+                resnr.append(int(line[21:27]))
+                elem.append(line[76:78].strip() if len(line) >= 77 else "")
+            elif "CRYST1" in line:
+                s = line.split()
+                box = np.array([float(s[1]), float(s[2]), float(s[3])])
+    name = os.path.basename(pdb_name).split(".")[0]
+    return dict(name=name, box=box, r=np.array(coords, dtype=float).reshape(-1, 3), atomnm=atomnm,
+                resnm=resnm, resnr=np.array(resnr, dtype=np.int64), elem=elem)
+
+
+def ReadTopFile(top_file, substitutions=None):
+    """Ewald/setup.jl:89-390: [ defaults ], [ atomtypes ], every [ moleculetype ] with its
+    [ atoms ] (from the file itself or from `#include "x.itp"` files next to it) and
+    [ molecules ].  Bonded sections are kept as raw token lists (nothing on the hot path reads
+    them).  `substitutions` replaces template tokens such as the deck's `SOL SOLNUMBER`; without
+    it a non-integer count raises like the reference's parse(Int64, ...).  Preprocessor lines
+    (#ifndef / #else / #endif) are skipped like any other line without a section meaning, i.e.
+    both branches are read -- the reference does the same."""
+    substitutions = substitutions or {}
+    top = dict(defaults=None, atomtypes=[], molparams=[], molecules={}, system=None)
+    state = dict(zone="?", mol=None)
+
+    def close_molecule():
+        if state["mol"] is not None and state["mol"]["atoms"]:
+            top["molparams"].append(state["mol"])
+        state["mol"] = None
+
+    def parse_lines(path):
+        with open(path) as fh:
+            for raw in fh:
+                line = raw.split(";")[0].strip()
+                if not line:
+                    continue
+                if line.startswith("#include"):
+                    parse_lines(os.path.join(os.path.dirname(path), line.split('"')[1]))
+                    continue
+                if line.startswith("#"):
+                    continue
+                if line.startswith("[") and line.endswith("]"):
+                    state["zone"] = line[1:-1].strip()
+                    if state["zone"] in ("moleculetype", "system", "molecules"):
+                        close_molecule()
+                    continue
+                s = line.split()
+                z = state["zone"]
+                if z == "defaults" and len(s) > 2:
+                    top["defaults"] = dict(nbfunc=int(s[0]), comb_rule=int(s[1]), gen_pairs=s[2],
+                                           fudgeLJ=float(s[3]), fudgeQQ=float(s[4]))
+                elif z == "atomtypes" and len(s) > 2:
+                    # name  bond_type  mass  charge  ptype  sigma(nm)  epsilon(kJ/mol)
+                    top["atomtypes"].append(dict(name=s[0], atomicnr=s[1], mass=float(s[2]),
+                                                 charge=float(s[3]), ptype=s[4], sigma=float(s[5]),
+                                                 epsilon=float(s[6])))
+                elif z == "moleculetype":
+                    state["mol"] = dict(name=s[0], nrexcl=int(s[1]), atoms=[], bonds=[], pairs=[],
+                                        angles=[], dihedrals=[])
+                elif z == "atoms" and len(s) > 2:
+                    state["mol"]["atoms"].append(dict(nr=int(s[0]), type=s[1], resnr=int(s[2]),
+                                                      resnm=s[3], atomnm=s[4], cgnr=int(s[5]),
+                                                      charge=float(s[6]), mass=float(s[7])))
+                elif z in ("bonds", "pairs", "angles", "dihedrals") and state["mol"] is not None:
+                    state["mol"][z].append(s)
+                elif z == "system":
+                    top["system"] = line
+                elif z == "molecules":
+                    tok = substitutions.get(s[1], s[1])
+                    top["molecules"][s[0]] = int(tok)
+
+    parse_lines(top_file)
+    close_molecule()
+    if len(top["molparams"]) != len(top["molecules"]):   # setup.jl:149-152
+        raise ValueError(f"The number of moleculetypes in topology file {top_file} does not match "
+                         "the number in section [ molecules ] of said file.")
+    return top
+
+
+def MakeTables(top):
+    """Nonbonded part of Ewald/setup.jl:546-673 + the unit conversion of main.jl:185-186:
+    Tables(eps, sig) mixing (structs.jl:337-347) over the [ atomtypes ] in file order, eps in K
+    (kJ/mol / R), sig in Angstrom (nm * 10).  Returns structs.Tables."""
+    from .structs import Tables
+    eps = np.array([a["epsilon"] for a in top["atomtypes"]])
+    sig = np.array([a["sigma"] for a in top["atomtypes"]])
+    t = Tables(eps, sig)
+    t.eps_ij = t.eps_ij / R_GAS
+    t.sig_ij = t.sig_ij * 10.0
+    return t
+
+
+def system_from_decks(pdb, top):
+    """MakeAtomArrays (setup.jl:393-445) reduced to what the hot path takes: for every PDB atom
+    its molecule type (residue name == moleculetype name, or the PDB's residue name among the
+    molecule's atom residue names), atom-type number (1-based index into [ atomtypes ]), charge
+    and mass from the molecule's [ atoms ]; molecules from consecutive residue numbers; COM by
+    mass.  Returns the arrays of Context.upload_system / Batch."""
+    type_no = {a["name"]: k + 1 for k, a in enumerate(top["atomtypes"])}
+    by_res = {}
+    for m in top["molparams"]:
+        by_res[m["name"]] = m
+        for a in m["atoms"]:
+            by_res.setdefault(a["resnm"], m)
+    resnr = np.asarray(pdb["resnr"])
+    resnr = resnr + (1 - resnr[0])                    # setup.jl:399-404
+    starts = np.flatnonzero(np.r_[True, resnr[1:] != resnr[:-1]])
+    first = starts + 1
+    last = np.r_[starts[1:], len(resnr)]
+    atype, charge, mass = [], [], []
+    for f, l in zip(first, last):
+        names = list(pdb["atomnm"][f - 1:l])
+        m = by_res.get(pdb["resnm"][f - 1])
+        if m is None:  # residue name unknown to the topology (mea.pdb: "MEA" vs "MEA_DUMMY"/"MOL"):
+            cands = [x for x in top["molparams"] if [a["atomnm"] for a in x["atoms"]] == names]
+            if len(cands) != 1:    # the reference resolves this through its global moleculeList
+                raise KeyError(f"residue {pdb['resnm'][f - 1]!r} matches no moleculetype")
+            m = cands[0]
+        for nm in names:
+            a = next(x for x in m["atoms"] if x["atomnm"] == nm)
+            atype.append(type_no[a["type"]])
+            charge.append(a["charge"])
+            mass.append(a["mass"])
+    mass = np.array(mass)
+    r = pdb["r"]
+    com = np.array([(r[f - 1:l] * mass[f - 1:l, None]).sum(0) / mass[f - 1:l].sum()
+                    for f, l in zip(first, last)])
+    tab = MakeTables(top)
+    return dict(com=com, coords=r.copy(), first_atom=first.astype(np.int64),
+                last_atom=last.astype(np.int64), atype=np.array(atype, dtype=np.int64),
+                charge=np.array(charge), mass=mass, eps=tab.eps_ij, sig=tab.sig_ij, box=pdb["box"])
+
+
+def PrintPDB(filename, step, coords, box, atom_names, mol_names, mol_numbers):
+    """Ewald/initialConfigurations.jl:160-181: `<filename>_<step>.pdb` with the reference's
+    CRYST1 / ATOM format strings (not strict PDB columns)."""
+    box = np.broadcast_to(np.asarray(box, dtype=float), (3,))
+    path = f"{filename}_{step}.pdb"
+    with open(path, "w") as fh:
+        fh.write("%-7s %7.3f %7.3f %7.3f %30s \n" % ("CRYST1", box[0], box[1], box[2],
+                                                      "90.00  90.00  90.00 P 1           1"))
+        for i, (xyz, an, mn, mol) in enumerate(zip(coords, atom_names, mol_names, mol_numbers), 1):
+            fh.write("%-6s %4d %3s %4s %5d %3s %7.3f %7.3f %7.3f %5.2f %5.2f \n"
+                     % ("ATOM", i, an, mn, mol, " ", xyz[0], xyz[1], xyz[2], 1.00, 0.00))
+    return path

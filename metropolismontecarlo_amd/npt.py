@@ -17,6 +17,8 @@ K, so beta = 1/T and the pressure is in K / A^3.
 """
 import math
 
+import numpy as np
+
 
 def VolumeChange(ctx, energy_old, box, n_mol, pressure, temperature, vmax, lj_rcut, qq_rcut, rng,
                  alpha=5.6):
@@ -46,3 +48,26 @@ def VolumeChange(ctx, energy_old, box, n_mol, pressure, temperature, vmax, lj_rc
     ctx.update_system(*saved)                      # ... and the exact old coordinates
     ctx.recip_long()                               # S(k) of the restored configuration
     return False, box, energy_old, None
+
+
+# ---- Lennard-Jones tail corrections (Ewald/energy.jl:514-614) --------------------------------------
+def ener_corr(eps, sig, r_cut, box, b):
+    """energy.jl:564-612 `ener_corr`: 8 pi / (3 V) * sum_ij b_i b_j eps_ij sig_ij^3
+    ((1/3) (sig_ij/r_c)^9 - (sig_ij/r_c)^3), b = number of atoms of each type."""
+    eps, sig, b = (np.asarray(x, dtype=float) for x in (eps, sig, b))
+    vol = float(box) ** 3
+    sig3 = sig ** 3
+    sigor3 = sig3 / float(r_cut) ** 3
+    coru = (b[:, None] * b[None, :] * eps * sig3 * ((1.0 / 3.0) * sigor3 ** 3 - sigor3)).sum()
+    return 8.0 * np.pi / (3.0 * vol) * coru
+
+
+def press_corr(eps, sig, r_cut, box, b):
+    """energy.jl:514-562 `press_corr`: 16 pi / (3 V^2) * sum_ij b_i b_j eps_ij sig_ij^3
+    ((2/3) (sig_ij/r_c)^9 - (sig_ij/r_c)^3)."""
+    eps, sig, b = (np.asarray(x, dtype=float) for x in (eps, sig, b))
+    vol = float(box) ** 3
+    sig3 = sig ** 3
+    sigor3 = sig3 / float(r_cut) ** 3
+    corp = (b[:, None] * b[None, :] * eps * sig3 * ((2.0 / 3.0) * sigor3 ** 3 - sigor3)).sum()
+    return 16.0 * np.pi / (3.0 * vol * vol) * corp
