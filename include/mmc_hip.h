@@ -232,6 +232,12 @@ int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
 /* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
  * r^2 in (0, 256): lets a test bound its error against an exact evaluation. */
 int32_t mmc_batch_qq_table(mmc_batch *b, const double *r2, int64_t n, double *out);
+/* Radial-distribution histogram over every replica of the batch: the intent of Ewald/gr.jl
+ * `makeRDF` with each replica as one frame.  One site per molecule -- site >= 0: that atom slot
+ * (0 = the oxygens of water), site < 0: the centre of mass (gr.jl's cm mode); all pairs i < j,
+ * gr.jl's minimum image (:75-80), bin = ceil(r / dr), dr = box / 2 / numbins (:5,87), counted
+ * when bin <= numbins.  hist[0 .. numbins] (numbins + 1 counters). */
+int32_t mmc_batch_rdf(mmc_batch *b, int32_t site, int32_t numbins, uint64_t *hist);
 /* Settle the last outstanding proposals without evaluating new ones. */
 int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
 

@@ -123,6 +123,7 @@ SIGNATURES = {
     "mmc_batch_set_option": [_vp, C.c_char_p, _i64],
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
+    "mmc_batch_rdf": [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
     "mmc_study_f32_total": [_vp, C.c_double, C.c_double, C.c_int32, _dp],
     "mmc_study_f32_move": [_vp, _i64, _dp, _dp, C.c_double, C.c_double, C.c_int32, _dp, _i32p],

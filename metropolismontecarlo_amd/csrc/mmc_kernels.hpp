@@ -500,3 +500,52 @@ __global__ void k_soa_to_aos(const double *x, const double *y, const double *z, 
         aos[3 * i] = x[i]; aos[3 * i + 1] = y[i]; aos[3 * i + 2] = z[i];
     }
 }
+
+// ---- radial distribution histogram (the intent of Ewald/gr.jl `makeRDF`) -------------------------
+// One site per molecule (site >= 0: atom slot of the molecule, e.g. 0 = the oxygens; site < 0: the
+// centre of mass, gr.jl's cm mode).  All pairs i < j of one replica, gr.jl's minimum image
+// (:75-80: strict < -side/2 -> + side, > side/2 -> - side), bin = ceil(r / dr) with
+// dr = side / 2 / numbins (:5,87), counted when bin <= numbins (:88-90).  hist[0 .. numbins]
+// (bin 0 only for coincident sites) is accumulated over the replicas of the launch.
+__global__ __launch_bounds__(MMC_BLOCK) void k_rdf(BatchView bv, int site, int numbins,
+                                                   unsigned long long *hist)
+{
+    extern __shared__ unsigned int sh_hist[];
+    const int r = blockIdx.x, n = bv.n_mol;
+    for (int k = threadIdx.x; k <= numbins; k += MMC_BLOCK)
+        sh_hist[k] = 0u;
+    __syncthreads();
+    const double side = bv.box, sideh = side / 2.0, dr = sideh / numbins;
+    auto load = [&](int j, double &x, double &y, double &z) {
+        if (site < 0) {
+            const int64_t m = r * bv.mol_stride + j;
+            x = bv.comx[m]; y = bv.comy[m]; z = bv.comz[m];
+        } else {
+            const int64_t a = r * bv.atom_stride + bv.first0[j] + site;
+            x = bv.ax[a]; y = bv.ay[a]; z = bv.az[a];
+        }
+    };
+    for (int i = 0; i < n - 1; i++) {
+        double xi, yi, zi;
+        load(i, xi, yi, zi);
+        for (int j = i + 1 + threadIdx.x; j < n; j += MMC_BLOCK) {
+            double xj, yj, zj;
+            load(j, xj, yj, zj);
+            double xx = xi - xj, yy = yi - yj, zz = zi - zj;
+            if (xx < -sideh) xx = xx + side;
+            if (xx > sideh) xx = xx - side;
+            if (yy < -sideh) yy = yy + side;
+            if (yy > sideh) yy = yy - side;
+            if (zz < -sideh) zz = zz + side;
+            if (zz > sideh) zz = zz - side;
+            const double rij = sqrt(xx * xx + yy * yy + zz * zz);
+            const double b = ceil(rij / dr);
+            if (b <= (double)numbins)
+                atomicAdd(&sh_hist[(int)b], 1u);
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k <= numbins; k += MMC_BLOCK)
+        if (sh_hist[k])
+            atomicAdd(&hist[k], (unsigned long long)sh_hist[k]);
+}

@@ -338,6 +338,13 @@ class Batch:
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
         return e, st.asdict()
 
+    def rdf(self, site, numbins):
+        """mmc_batch_rdf: histogram hist[0..numbins] of gr.jl's makeRDF over all replicas."""
+        hist = np.zeros(int(numbins) + 1, dtype=np.uint64)
+        check(self._L.mmc_batch_rdf(self._h, int(site), int(numbins),
+                                    hist.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return hist
+
     def new_chains(self, energies, virials=None, dr_max=0.15, dphi_max=0.05, set_value=0.5):
         """One mmc_chain record per replica (numpy structured array, _lib.CHAIN_DTYPE): the
         bookkeeping Loop() keeps in total / averages / trans_moves / rot_moves / totProps."""

@@ -77,3 +77,22 @@ def recip_long(kxyz, cfac, coords, charge, box):
 def recip_move_delta(kxyz, cfac, S_old, r_old, r_new, q, box):
     dS = structure_factor(kxyz, r_new, q, box) - structure_factor(kxyz, r_old, q, box)
     return float((cfac * (np.abs(S_old + dS) ** 2 - np.abs(S_old) ** 2)).sum())
+
+
+def make_rdf_hist(sites, side, numbins):
+    """Ewald/gr.jl:60-91 (`makeRDF`, the pair loop), literally: all pairs i < j, the file's own
+    minimum image (strict < -side/2 -> + side, > side/2 -> - side), bin = ceil(r / dr) with
+    dr = side / 2 / numbins, counted when bin <= numbins.  hist[0 .. numbins]."""
+    sites = np.asarray(sites, dtype=np.float64)
+    sideh = side / 2.0
+    dr = sideh / numbins
+    hist = np.zeros(numbins + 1, dtype=np.uint64)
+    for i in range(sites.shape[0] - 1):
+        d = sites[i] - sites[i + 1:]
+        d = np.where(d < -sideh, d + side, d)
+        d = np.where(d > sideh, d - side, d)
+        rij = np.sqrt(d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1] + d[:, 2] * d[:, 2])
+        b = np.ceil(rij / dr)
+        b = b[b <= numbins].astype(np.int64)
+        np.add.at(hist, b, 1)
+    return hist

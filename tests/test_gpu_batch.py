@@ -445,3 +445,31 @@ def test_device_moves_chains_adjust():
         d = com - a["com"]
         d -= a["box"] * np.round(d / a["box"])
         assert np.abs(d).max() < 4 * 1.25 + 1e-9
+
+
+def test_rdf_histogram_matches_gr_jl_restatement_bit_for_bit():
+    """mmc_batch_rdf against the numpy restatement of gr.jl's pair loop: integer counts, exact."""
+    from oracle import numpy_check
+    from metropolismontecarlo_amd import observables
+    a = common.nist_arrays(1, "unwrapped")
+    n_mol, box, numbins = a["com"].shape[0], a["box"], 100
+    with make_batch(a, 3) as b:
+        b.recip_long()
+        b.run(150, 298.15, 0.4, 0.2, seed=2, n_groups=1)          # replicas diverge
+        want_o = np.zeros(numbins + 1, dtype=np.uint64)
+        want_c = np.zeros(numbins + 1, dtype=np.uint64)
+        for r in range(3):
+            com, coords, _ = b.get_replica(r)
+            want_o += numpy_check.make_rdf_hist(coords[0::3], box, numbins)
+            want_c += numpy_check.make_rdf_hist(com, box, numbins)
+        got_o, got_c = b.rdf(0, numbins), b.rdf(-1, numbins)
+        assert np.array_equal(got_o, want_o) and np.array_equal(got_c, want_c)
+        assert got_o.sum() > 0 and got_o[:10].sum() == 0           # no O-O closer than 1 A
+        r_, g = observables.normalize_rdf(got_o, n_mol, box, 3)
+        assert r_[0] == pytest.approx(0.5 * box / 2 / numbins)
+        assert 1.5 < g.max() < 15.0 and 2.4 < r_[np.argmax(g)] < 3.2   # first O-O peak (noisy: 100 x 3)
+        from metropolismontecarlo_amd._lib import MMCError
+        with pytest.raises(MMCError, match="MMC_ERR_ARG"):
+            b.rdf(0, 0)
+        with pytest.raises(MMCError, match="MMC_ERR_ARG"):
+            b.rdf(3, 10)

@@ -107,3 +107,21 @@ def test_branch_free_minimum_image_equals_reference_form_bitwise():
         # the sign of a zero result is irrelevant (it is squared); everything else bit-identical
         assert mine == ref and (mine != 0.0 or ref == 0.0), (c1, c2, box, mine, ref)
         assert np.float64(mine).tobytes() == np.float64(ref).tobytes() or mine == 0.0
+
+
+def test_rdf_restatement_and_normalisation_on_an_ideal_gas():
+    """oracle/numpy_check.make_rdf_hist (gr.jl:60-91) + observables.normalize_rdf (gr.jl:92-104):
+    every pair inside side/2 is counted once, and uniformly random points give g(r) ~ 1."""
+    from oracle import numpy_check
+    from metropolismontecarlo_amd import observables
+    rng = np.random.default_rng(8)
+    side, n, numbins = 10.0, 1500, 25
+    pts = rng.random((n, 3)) * side
+    hist = numpy_check.make_rdf_hist(pts, side, numbins)
+    d = pts[:, None, :] - pts[None, :, :]
+    d -= side * np.round(d / side)
+    rr = np.sqrt((d ** 2).sum(-1))[np.triu_indices(n, 1)]
+    assert hist.sum() == (rr <= side / 2).sum()
+    assert hist[3] == ((rr > 2 * 0.2) & (rr <= 3 * 0.2)).sum()      # bin = ceil(r / dr), dr = 0.2
+    r_, g = observables.normalize_rdf(hist, n, side, 1)
+    assert np.allclose(r_[:2], [0.1, 0.3]) and abs(g[8:].mean() - 1.0) < 0.02
