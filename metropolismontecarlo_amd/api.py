@@ -12,7 +12,8 @@ last time (which `Loop` may have restored on rejection, main.jl:623-624): that i
 entries `Loop` can have changed.  Total-energy calls re-send all coordinates.  The structure-factor
 arrays live on the device; `RecipMove`/`RecipLong` write the result back into `ewald.sumQExpNew`/
 `sumQExpOld` and, before computing, push the host arrays if the caller rebound them (main.jl:621,628
-rebind them to copies) -- detected by object identity.  `sync_system(moa, soa)` forces a full
+rebind them to copies) -- detected by comparing their content with what the device was last
+given (object identity is recycled by the allocator).  `sync_system(moa, soa)` forces a full
 re-send after arbitrary host edits.
 
 Nothing here computes energies on the host: without the HIP library and a GPU every function
