@@ -271,7 +271,7 @@ def main():
             "move_kernel_launches_per_move": launches / max(st["moves"], 1),
             "stream_syncs_per_move": 0.0,
             "pcie_bytes_per_move": {"h2d": 1 if args.device_moves else 200, "d2h": 64}}
-        if not args.no_secondary:
+        if not args.no_secondary and world == 1:   # side measurements: single-GPU runs only
             # the same path at BASELINE's two named replica counts, on this rank's GPU:
             # configs[1] = one chain (latency-bound), configs[2] = 256 replicas over 8 GPUs = 32/GPU
             out["other_configs"] = {}
@@ -312,7 +312,7 @@ def main():
             ctx.close()
             out["other_configs"]["configs[3]: 10 000 SPC/E, NPT volume move (K6+K2+K3)"] = {
                 "ms_per_volume_move": 1e3 * dt4 / n_vol, "energy_K": e4}
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": mps, "unit": "moves/s", "cores": 1, "kind": "port",
