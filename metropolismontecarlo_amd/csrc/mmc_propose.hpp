@@ -139,6 +139,17 @@ __device__ inline void apply_xform(const MoveXform &x, const double *com, const 
     }
 }
 
+// n bytes from mapped pinned host memory into device memory (the per-step flag bytes).
+__global__ void k_fetch_bytes(uint8_t *dst, const uint8_t *src, int n)
+{
+    const int i = 4 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i + 3 < n && ((reinterpret_cast<uintptr_t>(src + i) | reinterpret_cast<uintptr_t>(dst + i)) & 3) == 0)
+        *reinterpret_cast<uint32_t *>(dst + i) = *reinterpret_cast<const uint32_t *>(src + i);
+    else
+        for (int k = i; k < n && k < i + 4; k++)
+            dst[k] = src[k];
+}
+
 // What a launch of k_propose needs.
 struct GenArgs {
     const double2 *steps; // [R] {dr_max, dphi_max} of the chain
