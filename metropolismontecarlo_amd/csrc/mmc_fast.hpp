@@ -447,8 +447,11 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
                 if (ab >= 9) { ab -= 9; n += 1; }
             }
         }
-        // LJ pass: only atom pairs with eps > 0.001
-        for (int g = tid; g < nt * n_ljp; g += MMC_BLOCK) {
+        // LJ pass: only atom pairs with eps > 0.001.  Items are dealt from the LAST thread down:
+        // at ~117 neighbours the Coulomb pass leaves wave 0 a fifth, nearly empty iteration
+        // (1044 = 4 x 256 + 20 items) while waves 2 and 3 are done after four -- they take the LJ
+        // items (no barrier in between), so this pass hides behind wave 0's tail.
+        for (int g = MMC_BLOCK - 1 - tid; g < nt * n_ljp; g += MMC_BLOCK) {
             int n = g, p = 0;
             if (n_ljp != 1) { // water has one LJ pair (O-O): skip the integer division
                 n = g / n_ljp;
