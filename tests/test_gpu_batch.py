@@ -473,3 +473,50 @@ def test_rdf_histogram_matches_gr_jl_restatement_bit_for_bit():
             b.rdf(0, 0)
         with pytest.raises(MMCError, match="MMC_ERR_ARG"):
             b.rdf(3, 10)
+
+
+def test_fast_kernel_with_several_lj_pairs_per_molecule_pair(orc):
+    """A homogeneous 3-site model whose three sites all carry LJ (9 LJ atom pairs per molecule
+    pair, three atom types) runs the LDS-tiled kernel with n_ljp = 9: chain of moves against the
+    oracle, both the one-workgroup and the split form."""
+    rng = np.random.default_rng(31)
+    a = common.random_system(150, 24.0, seed=31, na_choices=(3,), n_types=3)
+    n_mol = a["com"].shape[0]
+    a["atype"] = np.tile([1, 2, 3], n_mol).astype(np.int64)          # identical molecules
+    q = np.array([-0.8, 0.5, 0.3])
+    a["charge"] = np.tile(q, n_mol)
+    e, s = np.array([60.0, 25.0, 8.0]), np.array([3.1, 2.6, 2.2])   # every pair has eps > 0.001
+    a["eps"], a["sig"] = np.sqrt(e[:, None] * e[None, :]), (s[:, None] + s[None, :]) / 2
+    rcut = 9.0
+    for parts in (1, 3):
+        s_o = common.oracle_system(a)
+        ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
+        orc.recip_long(ew, s_o.coords, s_o.charge, s_o.box)
+        from metropolismontecarlo_amd import structs
+        from metropolismontecarlo_amd.device import Batch
+        with Batch(2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+                   5.6 / a["box"], structs.factor, rcut, rcut) as b:
+            b.set_option("kernel", 1)                                 # must qualify: homogeneous
+            b.set_option("parts", parts)
+            b.recip_long()
+            acc_prev = None
+            for step in range(12):
+                i = int(rng.integers(1, n_mol + 1))
+                d = (rng.random(3) - 0.5) * 0.4
+                c_new = s_o.com[i - 1] + d
+                a_new = s_o.coords[3 * (i - 1):3 * i] + d
+                out, ov = b.eval(np.full(2, i), np.tile(c_new, (2, 1)), np.tile(a_new, (2, 1, 1)),
+                                 accept_prev=acc_prev)
+                do, ovo = orc.trial_move(i, s_o, ew, rcut, rcut, c_new, a_new)
+                assert bool(ov[0]) == ovo and bool(ov[1]) == ovo
+                assert np.abs(out[0] - do).max() < TOL * (np.abs(do).max() + 1e4), (step, out[0], do)
+                assert np.array_equal(out[0], out[1])
+                accept = (step % 3 != 0) and not ovo
+                if accept:                                             # commit on both sides
+                    s_o.com[i - 1] = c_new
+                    s_o.coords[3 * (i - 1):3 * i] = a_new
+                    ew.sumQExpOld[:] = ew.sumQExpNew
+                else:
+                    ew.sumQExpNew[:] = ew.sumQExpOld
+                acc_prev = np.full(2, accept)
+            b.settle(acc_prev)
