@@ -164,12 +164,12 @@ def main():
         torch.cuda.synchronize()
 
     # initial total energy of every replica (also initialises S(k)): the M2 metric
-    b.potential_ewald()
+    b.potential_ewald(as_array=True)
     barrier()
     t0 = time.perf_counter()
-    tot = b.potential_ewald()
+    tot = b.potential_ewald(as_array=True)      # mmc_totals[R] written straight into numpy
     t_full = time.perf_counter() - t0
-    energies = np.array([t["energy"] for t in tot])
+    energies = tot["energy"].copy()
     e_start = energies.copy()
 
     # chain r of this rank has global index rank*R + r and draws from stream seed + r (the driver
@@ -190,9 +190,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     # consistency: running totals vs a full recompute (Poly/main.jl:232-235), outside the timing
-    tot2 = b.potential_ewald()
-    drift = float(np.max(np.abs(energies - np.array([t["energy"] for t in tot2]))
-                         / np.abs(energies)))
+    tot2 = b.potential_ewald(as_array=True)
+    drift = float(np.max(np.abs(energies - tot2["energy"]) / np.abs(energies)))
 
     # C1: the only collective -- max of the time, sums of the observables (RCCL all-reduce)
     local = dict(moves=st["moves"], accepted=st["trans_accept"] + st["rot_accept"],

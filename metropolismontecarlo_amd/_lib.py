@@ -65,6 +65,11 @@ class RunStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+# mmc_totals as a numpy record (Batch.potential_ewald(as_array=True): no per-replica Python objects)
+TOTALS_DTYPE = np.dtype([("energy", "f8"), ("virial", "f8"), ("coulomb", "f8"), ("lj", "f8"),
+                         ("real", "f8"), ("recip", "f8"), ("self", "f8"), ("n_overlap", "i4"),
+                         ("_pad", "i4")])
+
 # mmc_chain as a numpy record: one row per replica, passed by pointer
 CHAIN_DTYPE = np.dtype([("dr_max", "f8"), ("dphi_max", "f8"), ("energy", "f8"), ("virial", "f8"),
                         ("avg_energy", "f8"), ("avg_virial", "f8"), ("steps_taken", "i8"),
@@ -117,7 +122,7 @@ SIGNATURES = {
     "mmc_batch_set_replica": [_vp, _i64, _dp, _dp],
     "mmc_batch_get_replica": [_vp, _i64, _dp, _dp, _dp],
     "mmc_batch_recip_long": [_vp, _dp],
-    "mmc_batch_potential_ewald": [_vp, C.POINTER(Totals)],
+    "mmc_batch_potential_ewald": [_vp, _vp],  # mmc_totals[R]: a ctypes array or a numpy buffer
     "mmc_batch_eval": [_vp, C.POINTER(Move), C.POINTER(MoveResult)],
     "mmc_batch_set_parts": [_vp, _i32],
     "mmc_batch_set_option": [_vp, C.c_char_p, _i64],

@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import CHAIN_DTYPE, Move, MoveResult, RunParams, RunStats, Totals, check
+from ._lib import CHAIN_DTYPE, TOTALS_DTYPE, Move, MoveResult, RunParams, RunStats, Totals, check
 
 _dp = C.POINTER(C.c_double)
 _i64p = C.POINTER(C.c_int64)
@@ -286,7 +286,13 @@ class Batch:
         check(self._L.mmc_batch_recip_long(self._h, _d(e)))
         return e
 
-    def potential_ewald(self):
+    def potential_ewald(self, as_array=False):
+        """potential(..., "ewald") of every replica: a list of dicts, or with as_array=True one
+        numpy record array (_lib.TOTALS_DTYPE) filled in place by the library."""
+        if as_array:
+            out = np.zeros(self.R, dtype=TOTALS_DTYPE)
+            check(self._L.mmc_batch_potential_ewald(self._h, out.ctypes.data_as(C.c_void_p)))
+            return out
         t = (Totals * self.R)()
         check(self._L.mmc_batch_potential_ewald(self._h, t))
         return [x.asdict() for x in t]

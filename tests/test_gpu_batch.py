@@ -520,3 +520,14 @@ def test_fast_kernel_with_several_lj_pairs_per_molecule_pair(orc):
                     ew.sumQExpNew[:] = ew.sumQExpOld
                 acc_prev = np.full(2, accept)
             b.settle(acc_prev)
+
+
+def test_potential_ewald_record_array_equals_dict_list():
+    a = common.nist_arrays(1, "unwrapped")
+    with make_batch(a, 3) as b:
+        dicts = b.potential_ewald()
+        arr = b.potential_ewald(as_array=True)
+        assert arr.shape == (3,)
+        for r in range(3):
+            for key in ("energy", "virial", "coulomb", "lj", "real", "recip", "self", "n_overlap"):
+                assert arr[key][r] == dicts[r][key]
