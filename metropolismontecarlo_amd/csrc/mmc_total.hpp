@@ -248,6 +248,17 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
     const int r = blockIdx.y;
     const int kx = blockIdx.x / MMC_NKTAB, ky = blockIdx.x % MMC_NKTAB - 5;
     const int aky = ky < 0 ? -ky : ky;
+    // which kz of this (kx, ky) column survive 0 < k^2 < k_sq_max (ewalds.jl:57-66): 16 of the 66
+    // columns have none, the others 3..11 -- skip what is not there (workgroup-uniform bounds)
+    const int16_t *col = bv.kmap + (kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB;
+    int k_lo = MMC_NKTAB, k_hi = -1;
+    for (int k = 0; k < MMC_NKTAB; k++)
+        if (col[k] >= 0) {
+            k_lo = min(k_lo, k);
+            k_hi = max(k_hi, k);
+        }
+    if (k_hi < 0)
+        return;
     const double *myph = ph + (int64_t)r * bv.n_atoms * 6;
     double acc[2 * MMC_NKTAB];
 #pragma unroll
@@ -285,9 +296,11 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
         const cplx qxy = c_mul(c_rmul(q, ex), ey);
 #pragma unroll
         for (int k = 0; k < MMC_NKTAB; k++) {
-            const cplx t = c_mul(qxy, ez[k]);
-            acc[2 * k] += t.re;
-            acc[2 * k + 1] += t.im;
+            if (k >= k_lo && k <= k_hi) {
+                const cplx t = c_mul(qxy, ez[k]);
+                acc[2 * k] += t.re;
+                acc[2 * k + 1] += t.im;
+            }
         }
     }
     double tot[2 * MMC_NKTAB];
@@ -296,7 +309,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
         double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
 #pragma unroll
         for (int k = 0; k < MMC_NKTAB; k++) {
-            const int idx = bv.kmap[(kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB + k];
+            const int idx = col[k];
             if (idx >= 0) {
                 s0[2 * idx] = tot[2 * k]; s0[2 * idx + 1] = tot[2 * k + 1];
                 s1[2 * idx] = tot[2 * k]; s1[2 * idx + 1] = tot[2 * k + 1];
