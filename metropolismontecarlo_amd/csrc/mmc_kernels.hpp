@@ -139,6 +139,13 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long(BatchView bv)
     for (int k = 0; k < 2 * MMC_NKTAB; k++)
         acc[k] = 0.0;
     const int aky = ky < 0 ? -ky : ky;
+    // a column without any kz inside 0 < k^2 < k_sq_max (16 of the 66) has nothing to sum
+    const int16_t *col = bv.kmap + (kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB;
+    bool any = false;
+    for (int k = 0; k < MMC_NKTAB; k++)
+        any = any || col[k] >= 0;
+    if (!any)
+        return;
     for (int l = threadIdx.x; l < s.n_atoms; l += MMC_BLOCK) {
         const double q = s.charge[l];
         double sn, cs;
