@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Host-side vs device-side move generation sample the same ensemble: R chains per mode from the
+same start, same step sizes, mean energy per molecule after equilibration with its standard error.
+(A biased generator -- e.g. a rotation that is not uniform about the axis -- would shift the mean.)
+
+    python3 scripts/compare_generators.py [--replicas 512] [--equil 40] [--prod 40]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import common  # noqa: E402
+from metropolismontecarlo_amd import structs  # noqa: E402
+from metropolismontecarlo_amd.device import Batch  # noqa: E402
+
+
+def run(mode, a, R, equil, prod, seed):
+    n_mol, box = a["com"].shape[0], a["box"]
+    b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box, 5.6 / box,
+              structs.factor, 10.0, 10.0)
+    b.set_option("device_moves", mode)
+    e = b.potential_ewald(as_array=True)["energy"].copy()
+    e, _ = b.run(equil * n_mol, 298.15, 0.35, 0.45, seed, e, n_threads=4)
+    acc = np.zeros(R)
+    n_acc = 0
+    for blk in range(prod):
+        e, st = b.run(n_mol, 298.15, 0.35, 0.45, seed + 1 + blk, e, n_threads=4)
+        acc += e
+        n_acc += 1
+    drift = np.max(np.abs(e - b.potential_ewald(as_array=True)["energy"]) / np.abs(e))
+    b.close()
+    per_chain = acc / n_acc / n_mol
+    return per_chain.mean(), per_chain.std(ddof=1) / np.sqrt(R), (st["trans_accept"] + st["rot_accept"]) / st["moves"], drift
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--replicas", type=int, default=512)
+    ap.add_argument("--equil", type=int, default=40)
+    ap.add_argument("--prod", type=int, default=40)
+    args = ap.parse_args()
+    a = common.nist_arrays(4, "unwrapped")
+    res = {}
+    for name, mode in (("host", 0), ("device", 1)):
+        res[name] = run(mode, a, args.replicas, args.equil, args.prod, 4242)
+        print(f"{name:6s} moves: <E>/N = {res[name][0]:.2f} +- {res[name][1]:.2f} K, "
+              f"acceptance {res[name][2]:.3f}, drift {res[name][3]:.1e}")
+    d = res["host"][0] - res["device"][0]
+    s = np.hypot(res["host"][1], res["device"][1])
+    print(f"difference {d:.2f} +- {s:.2f} K ({abs(d) / s:.1f} sigma)")
+
+
+if __name__ == "__main__":
+    main()
