@@ -107,29 +107,39 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_total_pairs(BatchView bv, const d
 
     double a_lj = 0.0, a_v = 0.0, a_q = 0.0;
     int n_ovl = 0;
-    // ---- Coulomb pass: one lane per (molecule pair, a, b) (ewalds.jl:343-372) ----
-    for (int g = tid; g < total * 9; g += MMC_BLOCK) {
-        const int n = g / 9, ab = g - n * 9;
-        const int a = ab / 3, b = ab - 3 * a;
-        const int e = entry(n);
-        if (e & (2 << 12)) {
+    // ---- Coulomb pass: one lane per (molecule pair, a, b) (ewalds.jl:343-372), predicated like
+    // the move kernel's (a skipped term is added as +0.0) with incremental (pair, a, b) indices ----
+    const BoxConsts bc = box_consts(box);
+    {
+        int n = tid / 9, ab = tid - 9 * n; // g = 9 n + ab; g += 256 = 9 * 28 + 4
+        for (int g = tid; g < total * 9; g += MMC_BLOCK) {
+            const int a = (ab * 11) >> 5, b = ab - 3 * a;
+            const int e = entry(n);
             const int ii = (e >> 6) & 63, jj = e & 63;
             const double *pa = &sm.ti[ii * MMC_REC + 3 * a], *pb = &sm.tj[jj * MMC_REC + 3 * b];
-            const double rx = vector1D(pa[0], pb[0], box);
-            const double ry = vector1D(pa[1], pb[1], box);
-            const double rz = vector1D(pa[2], pb[2], box);
+            const double rx = vector1D(pa[0], pb[0], bc);
+            const double ry = vector1D(pa[1], pb[1], bc);
+            const double rz = vector1D(pa[2], pb[2], bc);
             const double rab2 = rx * rx + ry * ry + rz * rz;
             const double qq = sm.qq9[ab];
-            if ((rab2 < pp.ovr) && (qq < 0))
-                n_ovl = 1;
-            else if (rab2 < pp.qq_slack_sq)
-                a_q += qq * qq_pair(sm.qtab, rab2, pp.kappa);
+            const bool gq = (e & (2 << 12)) != 0;
+            const bool ov = gq && (rab2 < pp.ovr) && (qq < 0);
+            const bool in = gq && !ov && (rab2 < pp.qq_slack_sq);
+            double ev = qq_table_eval_clamped(sm.qtab, rab2);
+            if (__any(in && rab2 < MMC_QQ_UMIN)) {
+                if (rab2 < MMC_QQ_UMIN) ev = qq_pair(sm.qtab, rab2, pp.kappa);
+            }
+            a_q += in ? qq * ev : 0.0;
+            n_ovl |= ov ? 1 : 0;
+            n += 28;
+            ab += 4;
+            if (ab >= 9) { ab -= 9; n += 1; }
         }
     }
     // ---- LJ pass: atom pairs with eps > 0.001 (energy.jl:257-285) ----
     const int n_ljp = fc.n_ljp;
-    for (int g = tid; g < total * n_ljp; g += MMC_BLOCK) {
-        int n = g, p = 0;
+    for (int g = MMC_BLOCK - 1 - tid; g < total * n_ljp; g += MMC_BLOCK) { // last thread first:
+        int n = g, p = 0;                                  // the waves the Coulomb tail leaves idle
         if (n_ljp != 1) {
             n = g / n_ljp;
             p = g - n * n_ljp;
