@@ -100,7 +100,10 @@ def main():
     ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
     ap.add_argument("--threads", type=int, default=0,
                     help="host threads per GPU for the accept/reject (0 = min(4, cores / ranks))")
-    ap.add_argument("--kernel", type=int, default=1, help="1 = LDS-tiled kernel, 0 = generic")
+    ap.add_argument("--kernel", type=int, default=2,
+                    help="2 = wave per move (default), 1 = workgroup per move, 0 = generic")
+    ap.add_argument("--wave-wgs", type=int, default=0,
+                    help="workgroups of a kernel-2 launch (0 = library default)")
     ap.add_argument("--zero-copy-moves", type=int, default=0)
     ap.add_argument("--device-moves", type=int, default=1,
                     help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
@@ -155,6 +158,8 @@ def main():
     b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
               5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
     b.set_option("kernel", args.kernel)
+    if args.wave_wgs:
+        b.set_option("wave_wgs", args.wave_wgs)
     b.set_option("zero_copy_moves", args.zero_copy_moves)
     b.set_option("device_moves", args.device_moves)
 
@@ -177,15 +182,15 @@ def main():
     g0 = sharding.shard(R, rank)[0]
     ev = 0 if args.no_events else max(1, args.event_every)
     energies, _ = b.run(args.warmup, TEMPERATURE, DR_MAX, DPHI_MAX,
-                        sharding.replica_seed(g0, phase=0), energies,
+                        sharding.run_seed(phase=0), energies,
                         n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                        n_threads=args.threads, n_streams=args.streams)
+                        n_threads=args.threads, n_streams=args.streams, replica0=g0)
     barrier()
     t0 = time.perf_counter()
     energies, st = b.run(args.steps, TEMPERATURE, DR_MAX, DPHI_MAX,
-                         sharding.replica_seed(g0, phase=1), energies,
+                         sharding.run_seed(phase=1), energies,
                          n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                         n_threads=args.threads, n_streams=args.streams)
+                         n_threads=args.threads, n_streams=args.streams, replica0=g0)
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -249,7 +254,7 @@ def main():
             t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
             achieved = bytes_move * replicas_per_launch / t_launch / 1e9
             out["roofline"] = {
-                "kernel": "k_move_eval_fast" if args.kernel == 1 else "k_move_eval",
+                "kernel": {2: "k_move_eval_wave", 1: "k_move_eval_fast", 0: "k_move_eval"}[args.kernel],
                 "bound": "hbm", "achieved": achieved,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args, replicas_per_launch),

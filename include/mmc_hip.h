@@ -219,8 +219,13 @@ int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *res
 int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
 /* Tuning switches (no effect on results beyond summation order):
  *   "parts"            as mmc_batch_set_parts
- *   "kernel"           1 = LDS-tiled kernel with the erfc(kappa r)/r table (default when every
- *                      molecule has the same atom types and charges), 0 = generic kernel
+ *   "kernel"           2 = one wavefront per trial move, persistent workgroups, erfc(kappa r)/r
+ *                      table (default when every molecule has the same atom types and charges),
+ *                      1 = one workgroup per trial move (LDS-tiled, same table), 0 = generic
+ *   "wave_wgs"         workgroups of a kernel-2 launch (0 = 4 per compute unit)
+ *   "inject_torn"      N > 0: the native driver corrupts its first N copies of result records
+ *                      before checking them, as a torn PCIe write would (test hook: the check must
+ *                      refuse them and read again; mmc_run_stats.torn_records counts them)
  *   "zero_copy_moves"  1 = the kernel reads proposals from pinned host memory instead of an
  *                      H2D copy on the stream (lower latency for one replica, default 0)
  *   "device_moves"     1 = mmc_batch_run / mmc_batch_run_chains generate the trial moves on the
@@ -238,6 +243,12 @@ int32_t mmc_batch_qq_table(mmc_batch *b, const double *r2, int64_t n, double *ou
  * gr.jl's minimum image (:75-80), bin = ceil(r / dr), dr = box / 2 / numbins (:5,87), counted
  * when bin <= numbins.  hist[0 .. numbins] (numbins + 1 counters). */
 int32_t mmc_batch_rdf(mmc_batch *b, int32_t site, int32_t numbins, uint64_t *hist);
+/* Result hand-off check (test hook): 1 if the 64-byte move-result record at `part_out_64` carries
+ * launch stamp `stamp` and a matching checksum, else 0. */
+int32_t mmc_part_validate(const void *part_out_64, uint32_t stamp);
+/* Copy the raw 64-byte result record of (replica r, part) of the last mmc_batch_eval and the
+ * stamp of that launch (test hook for the hand-off check). */
+int32_t mmc_batch_peek_part(mmc_batch *b, int64_t r, int32_t part, void *out64, uint32_t *stamp);
 /* Settle the last outstanding proposals without evaluating new ones. */
 int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
 
@@ -248,7 +259,8 @@ typedef struct {
     double temperature;  /* K                                (Ewald/main.jl:62)  */
     double dr_max;       /* translation box width, Angstrom  (Ewald/main.jl:118) */
     double dphi_max;     /* max rotation angle, rad          (Ewald/main.jl:73)  */
-    uint64_t seed;       /* replica r draws from stream seed + r */
+    uint64_t seed;       /* key of the run's random streams: chain r draws from the stream
+                            (seed, replica0 + r) -- see "Random streams" below */
     int64_t n_steps;     /* trial moves per replica to run */
     int32_t n_groups;    /* replica groups pipelined on separate streams (>=1) */
     int32_t n_parts;     /* workgroups per replica-move (0 = choose) */
@@ -258,7 +270,19 @@ typedef struct {
     int32_t n_streams;   /* HIP streams the groups are spread over; 0 = choose (one per group with
                             host proposals, one for all with "device_moves") */
     int32_t _pad;
+    uint64_t replica0;   /* global index of this batch's replica 0 (a rank that owns chains
+                            [g0, g0 + R) of a larger ensemble passes g0): trajectories depend on
+                            (seed, global index) only, not on how chains are spread over GPUs */
 } mmc_run_params;
+
+/* Random streams.  Device-side proposals ("device_moves"): every draw is Philox4x32-10 with key =
+ * seed (64 bit) and counter = (step number (64 bit), slot, global replica index), so streams of
+ * different (seed, replica) pairs never coincide -- seeds that differ by less than the replica
+ * count do NOT alias.  The step number continues across calls on the same batch (the batch counts
+ * the steps it has run), so repeated runs with one seed do not replay their draws; the molecule
+ * of step s of a call is still s mod n_mol, as Loop() restarts its sweep (Ewald/main.jl:490).
+ * Host-side proposals: one xoshiro256++ stream per chain seeded from a hash of (seed, global
+ * replica index, steps already run). */
 
 typedef struct {
     int64_t moves, launches;
@@ -267,6 +291,8 @@ typedef struct {
     double kernel_ms;    /* sum of HIP-event durations of the move kernel (time_kernels) */
     double energy_sum;   /* sum over replicas of the running total energy at the end */
     int64_t timed_launches; /* launches that contributed to kernel_ms */
+    int64_t torn_records;   /* result records that carried the launch stamp but failed their
+                               checksum when first read (re-read until whole) */
 } mmc_run_stats;
 
 /* The driver's counter-based generator, exposed for known-answer tests and for callers that

@@ -50,7 +50,7 @@ class RunParams(C.Structure):
     _fields_ = [("temperature", C.c_double), ("dr_max", C.c_double), ("dphi_max", C.c_double),
                 ("seed", C.c_uint64), ("n_steps", C.c_int64), ("n_groups", C.c_int32),
                 ("n_parts", C.c_int32), ("time_kernels", C.c_int32), ("n_threads", C.c_int32),
-                ("n_streams", C.c_int32), ("_pad", C.c_int32)]
+                ("n_streams", C.c_int32), ("_pad", C.c_int32), ("replica0", C.c_uint64)]
 
 
 class RunStats(C.Structure):
@@ -59,7 +59,7 @@ class RunStats(C.Structure):
                 ("trans_accept", C.c_int64), ("rot_attempt", C.c_int64),
                 ("rot_accept", C.c_int64), ("overlaps", C.c_int64), ("wall_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("energy_sum", C.c_double),
-                ("timed_launches", C.c_int64)]
+                ("timed_launches", C.c_int64), ("torn_records", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -128,6 +128,8 @@ SIGNATURES = {
     "mmc_batch_set_option": [_vp, C.c_char_p, _i64],
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
+    "mmc_part_validate": [_vp, C.c_uint32],
+    "mmc_batch_peek_part": [_vp, _i64, _i32, _vp, C.POINTER(C.c_uint32)],
     "mmc_batch_rdf": [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)],
     "mmc_batch_run": [_vp, C.POINTER(RunParams), _dp, C.POINTER(RunStats)],
     "mmc_study_f32_total": [_vp, C.c_double, C.c_double, C.c_int32, _dp],

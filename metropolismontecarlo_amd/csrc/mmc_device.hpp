@@ -90,6 +90,15 @@ __device__ __forceinline__ double vector1D(double c1, double c2, const BoxConsts
     const double m = (fabs(d) < bc.half) ? 0.0 : copysign(1.0, d);
     return fma(m, bc.neg, d);
 }
+// |minimum image|, except that a wrapped component comes back as |d| - box (negative): its SQUARE
+// is bit for bit the square of vector1D's result, (|d| - L)^2 == (d -+ L)^2, which is all an r^2
+// needs.  4 VALU (sub, cmp |d|, cndmask, fma |d|) instead of 6.
+__device__ __forceinline__ double vector1D_abs(double c1, double c2, const BoxConsts &bc)
+{
+    const double d = fabs(c2 - c1);
+    const double m = (d < bc.half) ? 0.0 : 1.0;
+    return fma(m, bc.neg, d);
+}
 __device__ __forceinline__ double vector1D(double c1, double c2, double box)
 {
     return vector1D(c1, c2, box_consts(box));

@@ -60,6 +60,7 @@ struct FastConsts {
     int32_t ljp_ab[9];         // atom pairs (3a + b) with eps > 0.001 (energy.jl:270)
     int32_t n_ljp;
     double q[3];
+    double eps9[9], sig9[9];   // the LJ table by atom pair 3a + b (k_move_eval_wave)
 };
 
 // f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t in [-1, 1).
@@ -113,6 +114,29 @@ __device__ __forceinline__ double qq_pair(const double *tab, double u, double ka
     p = fma(p, -x2, 1.0 / 3.0);
     p = fma(p, -x2, 1.0);
     return rsqrt(u) - 1.1283791670955126 * kappa * p; // 2/sqrt(pi)
+}
+
+// The same series for callers that must not let its nine constants be hoisted out of their loop
+// into registers (k_move_eval_wave): every coefficient is made opaque where it is used, so it is
+// materialised inside the (cold) branch.
+__device__ __forceinline__ double opaque_f64(double c)
+{
+    asm volatile("" : "+v"(c));
+    return c;
+}
+__device__ __noinline__ double qq_pair_cold(double u, double kappa)
+{
+    const double x2 = kappa * kappa * u;
+    double p = opaque_f64(1.0 / (40320.0 * 17.0));
+    p = fma(p, -x2, opaque_f64(1.0 / (5040.0 * 15.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / (720.0 * 13.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / (120.0 * 11.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / (24.0 * 9.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / (6.0 * 7.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / (2.0 * 5.0)));
+    p = fma(p, -x2, opaque_f64(1.0 / 3.0));
+    p = fma(p, -x2, 1.0);
+    return rsqrt(u) - opaque_f64(1.1283791670955126) * kappa * p; // 2/sqrt(pi)
 }
 
 // Build the table: one thread per piece.  Chebyshev interpolation at 11 nodes of the exact
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     block_sum_wide<7>(v, sm.tile, sm.red, ovl0 | (ovl1 << 1), sm.wcnt);
     if (tid == 0) { // sm.red[0..6] are already in PartOut order
         const int of = sm.wcnt[0] | sm.wcnt[1] | sm.wcnt[2] | sm.wcnt[3];
-        sm.red[7] = pack_ovl(of & 1, (of >> 1) & 1, stamp);
+        sm.red[7] = pack_ovl(of & 1, (of >> 1) & 1, stamp, part_checksum(sm.red, stamp));
     }
     __syncthreads();
     store_part(out + (int64_t)r * n_parts + part, sm.red, tid);

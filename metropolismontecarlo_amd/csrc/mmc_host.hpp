@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/mmc_hip.h"
 #include "mmc_total.hpp"
+#include "mmc_wave.hpp"
 #include <string>
 #include <vector>
 
@@ -95,4 +96,5 @@ struct DeviceSystem {
 PairParams mmc_pair_params(double lj_rcut, double qq_rcut, double diameter, double ovr,
                            double kappa, bool bare);
 
+bool part_copy_checked(const PartOut *src, unsigned want_stamp, PartOut *dst);
 void mmc_combine_parts(const PartOut *parts, int n_parts, double factor, mmc_move_result *res);

@@ -265,16 +265,20 @@ struct MoveRec {
 struct PartOut {
     double lj_pot[2], lj_vir[2], qq_pot[2]; // [old, new] raw sums of this workgroup's j-range
     double recip;                           // sum_k cfac (|S_new|^2 - |S_old|^2), no factor
-    int32_t ovl[2];                         // overlap of the old / new state; ovl[1] also carries
-                                            // the launch stamp: (stamp << 1) | overlap_new
+    int32_t ovl[2];                         // bit 0: overlap of the old / new state; above it
+                                            // ovl[0] carries the record's checksum and ovl[1] the
+                                            // launch stamp (store_part, part_checksum)
 };
 static_assert(sizeof(PartOut) == 64, "PartOut is one 64-byte line");
 
-// A PartOut leaves the workgroup as ONE 64-byte store (4 lanes x 16 B of one instruction) into
-// pinned host memory.  The driver stamps every launch with its number and polls ovl[1]: the
-// moment a record carries the expected stamp it is complete and may be consumed -- no event, no
-// stream synchronisation, and the host starts on the first results while the launch still runs.
-// `w8`: the record as 8 words in LDS (7 sums + the two ints), complete before the call.
+// A PartOut leaves the wave as one store instruction of 4 lanes x 16 B into pinned host memory.
+// The driver stamps every launch with its number and polls ovl[1]; nothing (neither HIP nor PCIe)
+// promises that the four pieces land together or in order, so the record also carries a 31-bit
+// checksum of its seven sums and the stamp in ovl[0]: the host consumes a record only when the
+// stamp is the expected one AND the checksum of the bytes it copied out matches -- a torn record
+// (new stamp, some sums still from the previous launch) fails the checksum and is polled again.
+// No fence, no event, no stream synchronisation, and the host starts on the first results while
+// the launch still runs.  `w8`: the record as 8 words in LDS, complete before the call.
 #define MMC_STAMP_MASK 0x3fffffffu
 __device__ inline void store_part(PartOut *dst, const double *w8, int tid)
 {
@@ -282,9 +286,26 @@ __device__ inline void store_part(PartOut *dst, const double *w8, int tid)
         reinterpret_cast<double2 *>(dst)[tid] = make_double2(w8[2 * tid], w8[2 * tid + 1]);
 }
 
-__device__ inline double pack_ovl(int o0, int o1, unsigned stamp)
+// 31-bit checksum of a PartOut's seven sums and its launch stamp (FNV-1a over the 14 dwords with an
+// extra xor-shift per double); the same function on the device (writer) and the host (reader).
+__host__ __device__ inline uint32_t part_checksum(const double *w7, unsigned stamp)
 {
-    const unsigned lo = (unsigned)(o0 & 1), hi = ((stamp & MMC_STAMP_MASK) << 1) | (unsigned)(o1 & 1);
+    uint32_t c = 0x811C9DC5u ^ ((stamp & MMC_STAMP_MASK) * 0x9E3779B1u);
+    for (int k = 0; k < 7; k++) {
+        unsigned long long b;
+        __builtin_memcpy(&b, &w7[k], 8);
+        c = (c ^ (uint32_t)b) * 0x01000193u;
+        c = (c ^ (uint32_t)(b >> 32)) * 0x01000193u;
+        c ^= c >> 15;
+    }
+    return c & 0x7fffffffu;
+}
+
+// word 7 of the record: ovl[0] = checksum << 1 | overlap_old, ovl[1] = stamp << 1 | overlap_new
+__device__ inline double pack_ovl(int o0, int o1, unsigned stamp, uint32_t csum)
+{
+    const unsigned lo = (csum << 1) | (unsigned)(o0 & 1),
+                   hi = ((stamp & MMC_STAMP_MASK) << 1) | (unsigned)(o1 & 1);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
         pobuf[2] = po.lj_vir[0]; pobuf[3] = po.lj_vir[1];
         pobuf[4] = po.qq_pot[0]; pobuf[5] = po.qq_pot[1];
         pobuf[6] = po.recip;
-        pobuf[7] = pack_ovl(po.ovl[0], po.ovl[1], stamp);
+        pobuf[7] = pack_ovl(po.ovl[0], po.ovl[1], stamp, part_checksum(pobuf, stamp));
     }
     __syncthreads();
     store_part(out + (int64_t)r * n_parts + part, pobuf, tid);

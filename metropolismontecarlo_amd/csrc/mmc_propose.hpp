@@ -8,8 +8,10 @@
 //   rotation     quaternions.jl:52-74  random axis by rejection from the cube
 //                quaternions.jl:158-182 angle uniform in +-dphi_max about that axis
 // Randomness is counter based (Philox4x32-10, Salmon et al. SC'11): every draw is a pure function
-// of (seed + replica, step, slot), so the host can re-derive the move kind and take the
-// Metropolis uniform of the same step without any state, whatever the grouping of the replicas.
+// of (seed, global replica index, step, slot) -- key = seed, counter = (step, slot, replica) -- so
+// the host can re-derive the move kind and take the Metropolis uniform of the same step without
+// any state, whatever the grouping of the replicas, and streams of different (seed, replica)
+// pairs never coincide.
 #pragma once
 #include <stdint.h>
 
@@ -41,10 +43,16 @@ struct Uniform2 {
     double a, b;
 };
 
-__host__ __device__ inline Uniform2 mmc_draw(uint64_t chain_seed, uint64_t step, uint32_t slot)
+// One chain's stream: the run's seed and the chain's GLOBAL replica index.
+struct ChainKey {
+    uint64_t seed;
+    uint32_t replica;
+};
+
+__host__ __device__ inline Uniform2 mmc_draw(ChainKey ck, uint64_t step, uint32_t slot)
 {
-    const Philox x = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), slot, 0u,
-                                   (uint32_t)chain_seed, (uint32_t)(chain_seed >> 32));
+    const Philox x = philox4x32_10((uint32_t)step, (uint32_t)(step >> 32), slot, ck.replica,
+                                   (uint32_t)ck.seed, (uint32_t)(ck.seed >> 32));
     Uniform2 u;
     u.a = (double)((((uint64_t)x.v[0] << 32) | x.v[1]) >> 11) * 0x1.0p-53;
     u.b = (double)((((uint64_t)x.v[2] << 32) | x.v[3]) >> 11) * 0x1.0p-53;
@@ -52,12 +60,12 @@ __host__ __device__ inline Uniform2 mmc_draw(uint64_t chain_seed, uint64_t step,
 }
 
 // main.jl:516-517: `chose_move = rand()`, translation when < probability_of_move["translation"]
-__host__ __device__ inline int mmc_move_kind(uint64_t chain_seed, uint64_t step)
+__host__ __device__ inline int mmc_move_kind(ChainKey chain_seed, uint64_t step)
 {
     return mmc_draw(chain_seed, step, MMC_SLOT_KIND).a < 0.5 ? 0 : 1;
 }
 
-__host__ __device__ inline double mmc_metropolis_uniform(uint64_t chain_seed, uint64_t step)
+__host__ __device__ inline double mmc_metropolis_uniform(ChainKey chain_seed, uint64_t step)
 {
     return mmc_draw(chain_seed, step, MMC_SLOT_METROPOLIS).a;
 }
@@ -79,7 +87,7 @@ struct MoveXform {
     double Rm[3][3];   // rotation about the COM
 };
 
-__device__ inline MoveXform propose_xform(uint64_t cs, uint64_t step, double box, double dr_max,
+__device__ inline MoveXform propose_xform(ChainKey cs, uint64_t step, double box, double dr_max,
                                           double dphi_max, const double *com)
 {
     MoveXform x;
@@ -153,7 +161,9 @@ __global__ void k_fetch_bytes(uint8_t *dst, const uint8_t *src, int n)
 // What a launch of k_propose needs.
 struct GenArgs {
     const double2 *steps; // [R] {dr_max, dphi_max} of the chain
-    uint64_t seed;        // chain r draws from (seed + r, step)
+    uint64_t seed;        // chain r draws from ChainKey{seed, replica0 + r} at counter
+    uint64_t replica0;    // rng_off + step
+    int64_t rng_off;
     int64_t step0;        // first step generated by this launch
     int n_gen;            // steps generated: step0 .. step0 + n_gen - 1
     int ring;             // slots of the record ring; step s lives in slot s % ring
@@ -206,7 +216,8 @@ __global__ void k_propose(BatchView bv, const double *rec, MoveRec *ring, GenArg
     m.flags = 0;
     for (int q = 0; q < 3; q++) m.com_old[q] = com[q];
     for (int q = 0; q < 9; q++) m.atoms_old[q] = at[q];
-    const MoveXform x = propose_xform(ga.seed + (uint64_t)r, (uint64_t)step, bv.box, sz.x, sz.y, com);
+    const ChainKey ck{ ga.seed, (uint32_t)(ga.replica0 + (uint64_t)r) };
+    const MoveXform x = propose_xform(ck, (uint64_t)(ga.rng_off + step), bv.box, sz.x, sz.y, com);
     for (int q = 0; q < 3; q++) m.com_new[q] = x.com_new[q];
     for (int a = 0; a < 3; a++)
         apply_xform(x, com, &at[3 * a], &m.atoms_new[3 * a]);

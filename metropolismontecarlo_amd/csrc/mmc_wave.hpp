@@ -1,0 +1,383 @@
+// mmc_wave.hpp -- k_move_eval_wave: the per-move kernel (K1+K4) with ONE WAVEFRONT PER TRIAL MOVE.
+//
+// Why (profiles/round1_default_pmc_summary.json): the workgroup-per-move form
+// (k_move_eval_fast) spent 1542 VALU instructions in each of its four waves, 58 % of its wave
+// cycles parked at barriers / s_waitcnt, and ran at 0.64 of the algorithmic roofline.  Three
+// structural costs: (1) the chosen molecule's coordinates were lane-varying LDS reads (a, b and
+// the state differ per lane), (2) every pass dealt its items to 256 lanes, so the LJ pass ran at
+// 46 % and the reciprocal pass at 66 % lane utilisation and one wave carried a nearly empty fifth
+// Coulomb iteration, (3) eight barriers per move serialised the four waves.
+//
+// Here a wave owns a whole (replica, part) unit and never synchronises with another wave:
+//   * the chosen molecule (old and new state, 24 doubles) lives in SGPRs: every lane works on a
+//     different NEIGHBOUR, all lanes on the same atom pair (a, b) and state, so chosen atoms,
+//     q_a q_b and the LJ parameters are scalar operands of the VALU instructions;
+//   * lane n holds neighbour n's whole 96-byte record in registers (six 16-byte loads straight
+//     from HBM/L2, no LDS staging) and runs the 9 atom pairs x 2 states over it; the LJ term of a
+//     pair with eps > 0.001 reuses the Coulomb term's minimum-image vector and r^2;
+//   * the COM scan, the neighbour loop and the reciprocal loop each run at >= 90 % lane
+//     utilisation (750 / 768, 117 / 128, 337 / 384);
+//   * workgroups are persistent (grid = a few per CU, each wave loops over units), so the 14 KB
+//     erfc table is copied to LDS once per workgroup, not once per move, and launch tails vanish;
+//   * latency is hidden by the other resident waves, which are at unrelated points of their own
+//     moves -- no barrier ever lines them up.
+// Branch decisions (gates, overlap, slack) are the reference's comparisons on unfused arithmetic,
+// as in every other kernel here; only the summation order differs from k_move_eval_fast.
+#pragma once
+#include "mmc_fast.hpp"
+
+#define WV_WAVES 4   // waves (= units in flight) per workgroup
+#define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
+
+struct WaveShared {
+    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    cplx ptab[WV_WAVES][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
+    int32_t list[WV_WAVES][WV_LIST];
+    alignas(16) double pvw[WV_WAVES][12];    // pending commit of the unit's replica, record layout
+    alignas(16) double outw[WV_WAVES][8];    // the PartOut being assembled
+};
+
+// Orders this wave's own LDS traffic (a wave's DS instructions execute in order; this only stops
+// the compiler from moving accesses across the point).
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int lane_i32(int v, int src)
+{
+    return __builtin_amdgcn_readlane(v, src);
+}
+
+// lane `src`'s double as a wave-uniform value (two v_readlane_b32 -> an SGPR pair)
+__device__ __forceinline__ double lane_f64(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// grid: any number of workgroups of WV_WAVES waves; wave w of workgroup g handles units
+// g * WV_WAVES + w, + gridDim.x * WV_WAVES, ...  Unit u = (replica r_base + u / n_parts,
+// part u % n_parts); part semantics as k_move_eval (the last part of n_parts > 1 does the
+// reciprocal part, the others split the molecule range).
+__global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
+    BatchView bv, double *rec, const double *__restrict__ qq_tab,
+    const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
+    const MoveRec *__restrict__ prev, PartOut *out, int n_parts, PairParams pp, int r_base,
+    int n_units, const uint8_t *__restrict__ flagv, unsigned stamp)
+{
+    __shared__ __align__(16) WaveShared sm;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += WV_WAVES * 64)
+        sm.qtab[k] = qq_tab[k];
+    __syncthreads(); // the only workgroup barrier: from here on the waves are independent
+
+    const int n_mol = bv.n_mol, nkv = bv.nkvecs;
+    const double box = bv.box;
+    const BoxConsts bc = box_consts(box);
+    const int np = (n_parts == 1) ? 1 : n_parts - 1;
+    const int plen = (n_mol + np - 1) / np;
+    const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
+    int32_t *const list = sm.list[wv];
+    const double *const pvw = sm.pvw[wv];
+
+    for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
+        // `lane` is made opaque once per unit: without this LLVM hoists every lane-derived address
+        // and shuffle index of the body out of the persistent loop and holds them in registers
+        // for the kernel's whole lifetime (180 VGPRs instead of 128)
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
+        int rl = unit, part = 0;
+        if (n_parts != 1) {
+            rl = unit / n_parts;
+            part = unit - rl * n_parts;
+        }
+        const int r = r_base + rl;
+        const bool do_pairs = (n_parts == 1) || (part < n_parts - 1);
+        const bool do_recip = (n_parts == 1) || (part == n_parts - 1);
+        const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
+        const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
+        double *const myrec = rec + (int64_t)r * n_mol * MMC_REC;
+
+        // ---- the move record: one load instruction (lane t holds word t), then scalars ----
+        const double *mvp = reinterpret_cast<const double *>(cur + r);
+        double w = 0.0;
+        if (lane < MV_WORDS)
+            w = mvp[lane];
+        const int gflag = flagv ? __builtin_amdgcn_readfirstlane((int)flagv[r]) : -1;
+        const long long hdr = __double_as_longlong(w);
+        const int i0 = lane_i32((int)hdr, 0) - 1;
+        const int flags = gflag >= 0 ? gflag : lane_i32((int)(hdr >> 32), 0);
+        const bool commit = prev && (flags & 1);
+        const int scur = (flags >> 1) & 1;
+
+        // pending commit of the previous accepted move (main.jl:598-621): written by part 0;
+        // every reader of this launch substitutes the pending words for that molecule
+        int pend = -1;
+        if (commit) {
+            const double *pvp = reinterpret_cast<const double *>(prev + r);
+            double pw = 0.0;
+            if (lane < 9) pw = pvp[MV_AT_NEW + lane];
+            else if (lane < 12) pw = pvp[MV_COM_NEW + lane - 9];
+            else if (lane == 12) pw = pvp[0];
+            pend = lane_i32((int)__double_as_longlong(pw), 12) - 1;
+            if (lane < 12)
+                sm.pvw[wv][lane] = pw;
+            if (part == 0 && lane < 12) {
+                myrec[(int64_t)pend * MMC_REC + lane] = pw;
+                if (lane < 9) {
+                    const int a = lane / 3, d = lane % 3;
+                    (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + 3 * pend + a] = pw;
+                } else {
+                    const int d = lane - 9;
+                    (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = pw;
+                }
+            }
+            wave_sync();
+        }
+
+        double a_lj0 = 0, a_lj1 = 0, a_v0 = 0, a_v1 = 0, a_q0 = 0, a_q1 = 0, a_rec = 0;
+        unsigned long long ovm0 = 0, ovm1 = 0; // lanes that saw an overlap, old / new state
+
+        // ================= reciprocal part (ewalds.jl:718-826) =================
+        if (do_recip) {
+            // phase tables e^{i 2 pi k x / L}, k = -5..5, of the 3 moved atoms, old and new: 18 rows
+            {
+                const int t = lane < 18 ? lane : 0;
+                const int st = t / 9, q = t - 9 * st; // q = 3 l + d
+                const double x = __shfl(w, (st ? MV_AT_NEW : MV_AT_OLD) + q, 64);
+                if (lane < 18)
+                    phase_row(x, box, sm.ptab[wv][st][q / 3][q % 3]);
+            }
+            wave_sync();
+            const double *So = s_buf(bv, r, scur);
+            double *Sn = s_buf(bv, r, scur ^ 1);
+            const int n_it = (nkv + 63) >> 6;
+            // software pipeline: the loads of iteration it + 1 are in flight during iteration it
+            int k = lane;
+            int kp = 0;
+            double cf = 0.0;
+            double2 so = make_double2(0.0, 0.0);
+            if (k < nkv) {
+                kp = kpack[k]; cf = bv.cfac[k];
+                so = *reinterpret_cast<const double2 *>(So + 2 * k);
+            }
+            for (int it = 0; it < n_it; it++) {
+                const int k2 = k + 64;
+                int kp2 = 0;
+                double cf2 = 0.0;
+                double2 so2 = make_double2(0.0, 0.0);
+                if (k2 < nkv) {
+                    kp2 = kpack[k2]; cf2 = bv.cfac[k2];
+                    so2 = *reinterpret_cast<const double2 *>(So + 2 * k2);
+                }
+                if (k < nkv) {
+                    const int kx = kp & 15, ky = (kp >> 4) & 15, kz = (kp >> 8) & 15;
+                    double nr = so.x, ni = so.y;
+#pragma unroll
+                    for (int l = 0; l < 3; l++) {
+                        const cplx tn = c_mul(c_mul(sm.ptab[wv][1][l][0][5 + kx], sm.ptab[wv][1][l][1][ky]),
+                                              sm.ptab[wv][1][l][2][kz]);
+                        const cplx to = c_mul(c_mul(sm.ptab[wv][0][l][0][5 + kx], sm.ptab[wv][0][l][1][ky]),
+                                              sm.ptab[wv][0][l][2][kz]);
+                        nr += fc.q[l] * (tn.re - to.re); // ewalds.jl:805-814
+                        ni += fc.q[l] * (tn.im - to.im);
+                    }
+                    *reinterpret_cast<double2 *>(Sn + 2 * k) = make_double2(nr, ni);
+                    a_rec += cf * ((nr * nr - (-ni) * ni) - (so.x * so.x - (-so.y) * so.y)); // :817-821
+                }
+                k = k2; kp = kp2; cf = cf2; so = so2;
+            }
+            wave_sync(); // ptab is rewritten by this wave's next unit
+        }
+
+        // ================= pair part =================
+        if (do_pairs) {
+            // The chosen molecule stays in the register `w` (lane t = word t of the move record);
+            // its coordinates are pulled into SGPRs with v_readlane where they are used, so only
+            // the six doubles of the current atom a (both states) are live in the pair loop.
+            double cc[2][3]; // centres of mass, st 0 = old, 1 = proposal
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                cc[0][d] = lane_f64(w, MV_COM_OLD + d);
+                cc[1][d] = lane_f64(w, MV_COM_NEW + d);
+            }
+            const double *comx = bv.comx + r * bv.mol_stride, *comy = bv.comy + r * bv.mol_stride,
+                         *comz = bv.comz + r * bv.mol_stride;
+
+            // ---- neighbours list[0 .. cnt): lane n takes neighbour n0 + n ----
+            auto process = [&](int cnt) {
+                wave_sync();
+                for (int n0 = 0; n0 < cnt; n0 += 64) {
+                    const int n = n0 + lane;
+                    const int ent = n < cnt ? list[n] : 0; // idle lanes: molecule 0, no gate bit
+                    const int j = ent & ((1 << 27) - 1), f = (int)((unsigned)ent >> 27);
+                    double t[MMC_REC];
+                    const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC);
+#pragma unroll
+                    for (int q = 0; q < 6; q++) {
+                        const double2 v = src[q];
+                        t[2 * q] = v.x;
+                        t[2 * q + 1] = v.y;
+                    }
+                    if (j == pend) {
+#pragma unroll
+                        for (int q = 0; q < MMC_REC; q++)
+                            t[q] = pvw[q];
+                    }
+                    const bool g0 = (f & 4) != 0, g1 = (f & 8) != 0; // ewalds.jl:340 per state
+                    const bool l0 = (f & 1) != 0, l1 = (f & 2) != 0; // energy.jl:254 per state
+                    // one atom pair (a, b), both states.  The Coulomb term needs only r^2, and
+                    // (|d| - L)^2 == (d -+ L)^2 bit for bit, so the minimum image is taken on
+                    // |d| (4 instructions per component instead of 6); the signed vector is
+                    // rebuilt only inside the LJ branch, which few atom pairs enter.
+                    auto pair_ab = [&](int ab, double a0x, double a0y, double a0z, double a1x,
+                                       double a1y, double a1z, double bx, double by, double bz) {
+                        const double qq = fc.qq9[ab];
+                        const bool qneg = qq < 0; // uniform
+                        const double p0x = vector1D_abs(a0x, bx, bc), p0y = vector1D_abs(a0y, by, bc),
+                                     p0z = vector1D_abs(a0z, bz, bc);
+                        const double p1x = vector1D_abs(a1x, bx, bc), p1y = vector1D_abs(a1y, by, bc),
+                                     p1z = vector1D_abs(a1z, bz, bc);
+                        const double u0 = p0x * p0x + p0y * p0y + p0z * p0z;
+                        const double u1 = p1x * p1x + p1y * p1y + p1z * p1z;
+                        const bool ov0 = g0 && qneg && (u0 < pp.ovr); // ewalds.jl:359
+                        const bool ov1 = g1 && qneg && (u1 < pp.ovr);
+                        const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq); // ewalds.jl:362
+                        const bool in1 = g1 && !ov1 && (u1 < pp.qq_slack_sq);
+                        double e0 = qq_table_eval_clamped(sm.qtab, u0);
+                        double e1 = qq_table_eval_clamped(sm.qtab, u1);
+                        // like charges closer than 0.5 A: the series (practically never taken)
+                        if (__any((in0 && u0 < MMC_QQ_UMIN) || (in1 && u1 < MMC_QQ_UMIN))) {
+                            if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
+                            if (u1 < MMC_QQ_UMIN) e1 = qq_pair_cold(u1, pp.kappa);
+                        }
+                        a_q0 = fma(e0, in0 ? qq : 0.0, a_q0); // ewalds.jl:365-367
+                        a_q1 = fma(e1, in1 ? qq : 0.0, a_q1);
+                        ovm0 |= __ballot(ov0);
+                        ovm1 |= __ballot(ov1);
+                        const double eps = fc.eps9[ab], sg = fc.sig9[ab];
+                        if (eps > 0.001) { // uniform (energy.jl:270); same r^2
+                            if (l0 && u0 < pp.lj_slack_sq) {
+                                const double s2 = sg * sg / u0;
+                                const double s6 = s2 * s2 * s2;
+                                const double s12 = s6 * s6;
+                                const double virab = eps * (2.0 * s12 - s6);
+                                const double f0 = vector1D(a0x, bx, bc) * virab * s2,
+                                             f1 = vector1D(a0y, by, bc) * virab * s2,
+                                             f2 = vector1D(a0z, bz, bc) * virab * s2;
+                                a_lj0 += eps * (s12 - s6);
+                                // COM vector of the virial (energy.jl:248-250, :279-281)
+                                a_v0 += vector1D(cc[0][0], t[9], bc) * f0
+                                        + vector1D(cc[0][1], t[10], bc) * f1
+                                        + vector1D(cc[0][2], t[11], bc) * f2;
+                            }
+                            if (l1 && u1 < pp.lj_slack_sq) {
+                                const double s2 = sg * sg / u1;
+                                const double s6 = s2 * s2 * s2;
+                                const double s12 = s6 * s6;
+                                const double virab = eps * (2.0 * s12 - s6);
+                                const double f0 = vector1D(a1x, bx, bc) * virab * s2,
+                                             f1 = vector1D(a1y, by, bc) * virab * s2,
+                                             f2 = vector1D(a1z, bz, bc) * virab * s2;
+                                a_lj1 += eps * (s12 - s6);
+                                a_v1 += vector1D(cc[1][0], t[9], bc) * f0
+                                        + vector1D(cc[1][1], t[10], bc) * f1
+                                        + vector1D(cc[1][2], t[11], bc) * f2;
+                            }
+                        }
+                    };
+#pragma unroll 1
+                    for (int a = 0; a < 3; a++) {
+                        const double a0x = lane_f64(w, MV_AT_OLD + 3 * a),
+                                     a0y = lane_f64(w, MV_AT_OLD + 3 * a + 1),
+                                     a0z = lane_f64(w, MV_AT_OLD + 3 * a + 2),
+                                     a1x = lane_f64(w, MV_AT_NEW + 3 * a),
+                                     a1y = lane_f64(w, MV_AT_NEW + 3 * a + 1),
+                                     a1z = lane_f64(w, MV_AT_NEW + 3 * a + 2);
+                        // the three b are written out (static register indices) but scheduled one
+                        // after the other: interleaving them costs 40 more VGPRs
+                        pair_ab(3 * a, a0x, a0y, a0z, a1x, a1y, a1z, t[0], t[1], t[2]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        pair_ab(3 * a + 1, a0x, a0y, a0z, a1x, a1y, a1z, t[3], t[4], t[5]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        pair_ab(3 * a + 2, a0x, a0y, a0z, a1x, a1y, a1z, t[6], t[7], t[8]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                wave_sync();
+            };
+
+            // ---- COM gates of both states (energy.jl:248-254, ewalds.jl:334-340): lane per
+            // molecule, survivors appended to the list in ascending j; two 64-molecule blocks of
+            // centres of mass are always in flight ahead of the one being tested ----
+            int base = j_begin;
+            while (base < j_end) {
+                int cnt = 0;
+                double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+                {
+                    const int ja = base + lane, jb = base + 64 + lane;
+                    if (ja < j_end) { ax = comx[ja]; ay = comy[ja]; az = comz[ja]; }
+                    if (jb < j_end) { bx = comx[jb]; by = comy[jb]; bz = comz[jb]; }
+                }
+                while (base < j_end && cnt <= WV_LIST - 64) {
+                    double cx = 0, cy = 0, cz = 0;
+                    const int jc = base + 128 + lane;
+                    if (jc < j_end) { cx = comx[jc]; cy = comy[jc]; cz = comz[jc]; }
+                    const int j = base + lane;
+                    if (pend >= base && pend < base + 64) { // uniform: at most one block per unit
+                        if (j == pend) { ax = pvw[9]; ay = pvw[10]; az = pvw[11]; }
+                    }
+                    int f = 0;
+                    {
+                        double r2[2];
+#pragma unroll
+                        for (int st = 0; st < 2; st++) {
+                            const double dx = vector1D_abs(cc[st][0], ax, bc);
+                            const double dy = vector1D_abs(cc[st][1], ay, bc);
+                            const double dz = vector1D_abs(cc[st][2], az, bc);
+                            r2[st] = dx * dx + dy * dy + dz * dz;
+                        }
+                        if (same_gate) { // one cutoff for both terms (the reference's set-up)
+                            f = ((r2[0] < pp.lj_gate_sq) ? 5 : 0) | ((r2[1] < pp.lj_gate_sq) ? 10 : 0);
+                        } else {
+                            f = ((r2[0] < pp.lj_gate_sq) ? 1 : 0) | ((r2[1] < pp.lj_gate_sq) ? 2 : 0) // energy.jl:254
+                                | ((r2[0] < pp.qq_gate_sq) ? 4 : 0) | ((r2[1] < pp.qq_gate_sq) ? 8 : 0); // ewalds.jl:340
+                        }
+                        if (j >= j_end || j == i0)
+                            f = 0;
+                    }
+                    const unsigned long long m = __ballot(f != 0);
+                    if (f)
+                        list[cnt + lanes_below(m)] = j | (f << 27);
+                    cnt += __popcll(m);
+                    ax = bx; ay = by; az = bz;
+                    bx = cx; by = cy; bz = cz;
+                    base += 64;
+                }
+                if (cnt)
+                    process(cnt);
+            }
+        }
+
+        // ---- wave reduction (fixed order: bitwise reproducible) and the 64-byte result ----
+        const double s0 = wave_sum(a_lj0), s1 = wave_sum(a_lj1), s2 = wave_sum(a_v0),
+                     s3 = wave_sum(a_v1), s4 = wave_sum(a_q0), s5 = wave_sum(a_q1),
+                     s6 = wave_sum(a_rec);
+        const int o0 = ovm0 != 0ULL, o1 = ovm1 != 0ULL;
+        if (lane == 0) {
+            double *o = sm.outw[wv];
+            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = s6;
+            o[7] = pack_ovl(o0, o1, stamp, part_checksum(o, stamp));
+        }
+        wave_sync();
+        store_part(out + (int64_t)r * n_parts + part, sm.outw[wv], lane);
+        wave_sync();
+    }
+}

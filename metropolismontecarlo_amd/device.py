@@ -335,14 +335,27 @@ class Batch:
         return out
 
     def run(self, n_steps, temperature, dr_max, dphi_max, seed, energies=None, n_groups=2,
-            n_parts=0, time_kernels=False, n_threads=1, n_streams=0):
+            n_parts=0, time_kernels=False, n_threads=1, n_streams=0, replica0=0):
+        """mmc_batch_run.  Chain r draws from the stream (seed, replica0 + r): `replica0` is the
+        global index of this batch's first chain when an ensemble is spread over several GPUs."""
         p = RunParams(float(temperature), float(dr_max), float(dphi_max), int(seed), int(n_steps),
                       int(n_groups), int(n_parts), int(time_kernels), int(n_threads),
-                      int(n_streams), 0)
+                      int(n_streams), 0, int(replica0))
         st = RunStats()
         e = np.zeros(self.R) if energies is None else _f64(energies).copy()
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
         return e, st.asdict()
+
+    def peek_part(self, r, part):
+        """(64 raw bytes, stamp) of the result record of (replica r, part) of the last eval()."""
+        buf = (C.c_uint8 * 64)()
+        stamp = C.c_uint32()
+        check(self._L.mmc_batch_peek_part(self._h, int(r), int(part), buf, C.byref(stamp)))
+        return bytes(buf), stamp.value
+
+    def part_validate(self, raw64, stamp):
+        buf = (C.c_uint8 * 64).from_buffer_copy(raw64)
+        return bool(self._L.mmc_part_validate(buf, int(stamp)))
 
     def rdf(self, site, numbins):
         """mmc_batch_rdf: histogram hist[0..numbins] of gr.jl's makeRDF over all replicas."""
@@ -362,12 +375,13 @@ class Batch:
         return c
 
     def run_chains(self, chains, n_steps, temperature, seed, adjust=True, n_groups=2, n_parts=0,
-                   time_kernels=False, n_threads=1, n_streams=0):
+                   time_kernels=False, n_threads=1, n_streams=0, replica0=0):
         """mmc_batch_run_chains: `chains` (from new_chains) is updated in place."""
         if chains.dtype != CHAIN_DTYPE or chains.shape != (self.R,) or not chains.flags.c_contiguous:
             raise ValueError("chains must be the array returned by new_chains()")
         p = RunParams(float(temperature), 0.0, 0.0, int(seed), int(n_steps), int(n_groups),
-                      int(n_parts), int(time_kernels), int(n_threads), int(n_streams), 0)
+                      int(n_parts), int(time_kernels), int(n_threads), int(n_streams), 0,
+                      int(replica0))
         st = RunStats()
         check(self._L.mmc_batch_run_chains(self._h, C.byref(p), chains.ctypes.data_as(C.c_void_p),
                                            int(bool(adjust)), C.byref(st)))

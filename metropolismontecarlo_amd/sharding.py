@@ -31,10 +31,17 @@ def shard_total(total_replicas, rank, world):
 
 
 def replica_seed(global_index, phase=0):
-    """RNG stream of a chain depends on its GLOBAL index only, so a chain's trajectory does not
-    depend on how many GPUs the ensemble is spread over.  `phase` separates warm-up from the
-    timed run."""
+    """Seed of a host-side (numpy) stream of one chain: depends on its GLOBAL index only, so a
+    chain's trajectory does not depend on how many GPUs the ensemble is spread over.  `phase`
+    separates warm-up from the timed run.  (The native driver does not add indices to seeds: it
+    keys its streams by the pair (seed, global replica index) -- pass run_seed(phase) as `seed`
+    and the shard's first global index as `replica0`.)"""
     return BASE_SEED + int(global_index) + 1_000_003 * int(phase)
+
+
+def run_seed(phase=0):
+    """`seed` of mmc_batch_run for one phase of a run; the same on every rank."""
+    return BASE_SEED + 1_000_003 * int(phase)
 
 
 def reduce_observables(local, elapsed, dist=None, device="cpu"):

@@ -47,15 +47,32 @@ def test_no_cxx_or_torch_types_in_the_abi():
     assert "liboracle" not in needed and "mmc_oracle" not in needed
 
 
-def test_struct_layouts_match_header():
-    # mmc_move: int32 mol, int32 accept_prev, double[3], double[9]; mmc_move_result: 4 doubles + 2 int32
-    assert C.sizeof(_lib.Move) == 8 + 24 + 72
-    assert _lib.Move.com_new.offset == 8 and _lib.Move.atoms_new.offset == 32
-    assert C.sizeof(_lib.MoveResult) == 40
-    assert C.sizeof(_lib.Totals) == 64
-    assert C.sizeof(_lib.RunParams) == 64
-    assert C.sizeof(_lib.RunStats) == 88
-    assert _lib.CHAIN_DTYPE.itemsize == 144        # mmc_chain: 18 eight-byte fields
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof / offsetof of every struct of the header, as gcc lays them out, against the ctypes
+    and numpy mirrors the Python side passes by pointer."""
+    prog = tmp_path / "layout.c"
+    prog.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "mmc_hip.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu\\n", sizeof(mmc_move), offsetof(mmc_move, com_new), offsetof(mmc_move, atoms_new));\n'
+        'printf("%zu %zu\\n", sizeof(mmc_move_result), sizeof(mmc_totals));\n'
+        'printf("%zu %zu %zu\\n", sizeof(mmc_run_params), offsetof(mmc_run_params, n_streams), offsetof(mmc_run_params, replica0));\n'
+        'printf("%zu %zu %zu\\n", sizeof(mmc_run_stats), offsetof(mmc_run_stats, timed_launches), offsetof(mmc_run_stats, torn_records));\n'
+        'printf("%zu %zu\\n", sizeof(mmc_chain), offsetof(mmc_chain, trans_set_value));\n'
+        "return 0;}\n")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.dirname(HEADER), str(prog), "-o", str(exe)])
+    rows = [list(map(int, l.split())) for l in subprocess.check_output([str(exe)], text=True).splitlines()]
+    assert rows[0] == [C.sizeof(_lib.Move), _lib.Move.com_new.offset, _lib.Move.atoms_new.offset]
+    assert rows[0] == [8 + 24 + 72, 8, 32]
+    assert rows[1] == [C.sizeof(_lib.MoveResult), C.sizeof(_lib.Totals)] == [40, 64]
+    assert rows[1][1] == _lib.TOTALS_DTYPE.itemsize
+    assert rows[2] == [C.sizeof(_lib.RunParams), _lib.RunParams.n_streams.offset,
+                       _lib.RunParams.replica0.offset]
+    assert rows[3] == [C.sizeof(_lib.RunStats), _lib.RunStats.timed_launches.offset,
+                       _lib.RunStats.torn_records.offset]
+    assert rows[4] == [_lib.CHAIN_DTYPE.itemsize, _lib.CHAIN_DTYPE.fields["trans_set_value"][1]]
+    assert rows[4][0] == 144                       # mmc_chain: 18 eight-byte fields
 
 
 def test_header_cites_reference_lines():

@@ -50,7 +50,7 @@ def oracle_chain(orc, a, moves, accept_rule):
     return out, s, ew
 
 
-@pytest.mark.parametrize("kernel", [1, 0])
+@pytest.mark.parametrize("kernel", [2, 1, 0])
 @pytest.mark.parametrize("k,variant,parts", [(1, "reference", 1), (1, "reference", 4),
                                              (4, "reference", 0), (4, "unwrapped", 9),
                                              (2, "unwrapped", 2), (3, "reference", 16)])
@@ -73,7 +73,7 @@ def test_batch_eval_chain(k, variant, parts, kernel, orc):
     with make_batch(a, R) as b:
         if parts:
             b.set_parts(parts)
-        b.set_option("kernel", kernel)   # 1: LDS-tiled + erfc table (default), 0: generic
+        b.set_option("kernel", kernel)   # 2: wave per move (default), 1: workgroup per move, 0: generic
         b.set_option("zero_copy_moves", k % 2)
         e0 = b.recip_long()
         ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
@@ -109,7 +109,8 @@ def test_batch_parts_agree(orc):
     g = common.golden(4, "unwrapped")
     mv = g["moves"][0]
     ref = None
-    for parts, kernel in ((1, 1), (2, 1), (3, 0), (5, 1), (9, 0), (16, 1), (1, 0)):
+    for parts, kernel in ((1, 2), (2, 2), (1, 1), (2, 1), (3, 0), (5, 2), (9, 0), (16, 2),
+                          (16, 1), (1, 0)):
         with make_batch(a, 2) as b:
             b.set_parts(parts)
             b.set_option("kernel", kernel)
@@ -182,8 +183,8 @@ def test_non_homogeneous_system_uses_generic_kernel(orc):
 
 
 @pytest.mark.parametrize("R,groups,parts,threads,kernel",
-                         [(1, 1, 0, 1, 1), (5, 2, 0, 1, 1), (16, 3, 1, 3, 1), (8, 2, 4, 2, 0),
-                          (12, 4, 0, 2, 1)])
+                         [(1, 1, 0, 1, 2), (5, 2, 0, 1, 2), (16, 3, 1, 3, 2), (8, 2, 4, 2, 0),
+                          (12, 4, 0, 2, 1), (9, 2, 3, 2, 2)])
 def test_engine_running_total_vs_recompute(R, groups, parts, threads, kernel, orc):
     """The reference's only integration invariant (Poly/main.jl:232-235): the running total
     energy (initial + accepted deltas) equals a full recompute -- here after hundreds of native
@@ -317,8 +318,8 @@ def test_engine_chains_bookkeeping_and_adjust():
 
 # ---- device-side move generation ------------------------------------------------
 @pytest.mark.parametrize("R,groups,parts,threads,kernel,zero_copy",
-                         [(1, 1, 0, 1, 1, 0), (7, 2, 0, 2, 1, 0), (16, 3, 1, 3, 1, 1),
-                          (8, 2, 4, 2, 0, 0)])
+                         [(1, 1, 0, 1, 2, 0), (7, 2, 0, 2, 2, 0), (16, 3, 1, 3, 2, 1),
+                          (8, 2, 4, 2, 0, 0), (6, 2, 0, 2, 1, 0)])
 def test_device_moves_running_total_vs_recompute(R, groups, parts, threads, kernel, zero_copy, orc):
     """Same invariant as test_engine_running_total_vs_recompute with the proposals drawn on the
     device: the move kernel, the commit and S(k) see exactly the coordinates k_propose wrote."""
@@ -488,7 +489,7 @@ def test_fast_kernel_with_several_lj_pairs_per_molecule_pair(orc):
     e, s = np.array([60.0, 25.0, 8.0]), np.array([3.1, 2.6, 2.2])   # every pair has eps > 0.001
     a["eps"], a["sig"] = np.sqrt(e[:, None] * e[None, :]), (s[:, None] + s[None, :]) / 2
     rcut = 9.0
-    for parts in (1, 3):
+    for parts, kernel in ((1, 2), (3, 2), (1, 1), (3, 1)):
         s_o = common.oracle_system(a)
         ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
         orc.recip_long(ew, s_o.coords, s_o.charge, s_o.box)
@@ -496,7 +497,7 @@ def test_fast_kernel_with_several_lj_pairs_per_molecule_pair(orc):
         from metropolismontecarlo_amd.device import Batch
         with Batch(2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
                    5.6 / a["box"], structs.factor, rcut, rcut) as b:
-            b.set_option("kernel", 1)                                 # must qualify: homogeneous
+            b.set_option("kernel", kernel)                            # must qualify: homogeneous
             b.set_option("parts", parts)
             b.recip_long()
             acc_prev = None
