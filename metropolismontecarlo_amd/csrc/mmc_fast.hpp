@@ -32,6 +32,9 @@
 
 #define MMC_TILE 150      // neighbours staged per LDS tile (14 KB; doubles as reduction scratch)
 #define MMC_REC 12        // doubles per molecule record: 9 atom coordinates + 3 COM
+#define MMC_RSTRIDE 16    // doubles between records in HBM: every record is one 128-byte line
+                          // (at a 96-byte stride half of them straddled two lines and a gather
+                          // fetched 1.5 lines per record)
 #define MMC_QQ_DEG 10
 #define MMC_QQ_NCOEF (MMC_QQ_DEG + 1)
 #define MMC_QQ_NINT 160   // 10 octaves [2^-2, 2^8) x 16 sub-intervals
@@ -198,7 +201,7 @@ __global__ void k_build_rec(BatchView bv, double *rec, int r)
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= bv.n_mol)
         return;
-    double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_REC;
+    double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_RSTRIDE;
     const int64_t a0 = r * bv.atom_stride + bv.first0[j], m0 = r * bv.mol_stride + j;
 #pragma unroll
     for (int a = 0; a < 3; a++) {
@@ -207,6 +210,7 @@ __global__ void k_build_rec(BatchView bv, double *rec, int r)
     o[9] = bv.comx[m0]; o[10] = bv.comy[m0]; o[11] = bv.comz[m0];
 }
 
+// (per_replica = n_mol * MMC_RSTRIDE doubles)
 __global__ void k_broadcast_rec(double *rec, int64_t per_replica)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     const double box = bv.box;
     const double *comx = bv.comx + r * bv.mol_stride, *comy = bv.comy + r * bv.mol_stride,
                  *comz = bv.comz + r * bv.mol_stride;
-    double *myrec = rec + (int64_t)r * n_mol * MMC_REC;
+    double *myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
     const bool do_pairs = (n_parts == 1) || (part < n_parts - 1);
     const bool do_recip = (n_parts == 1) || (part == n_parts - 1);
     const int np = (n_parts == 1) ? 1 : n_parts - 1;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     // reader in this launch substitutes the pending words for that molecule.
     if (part == 0 && commit && tid < 12) {
         const double v = pd_word(tid);
-        myrec[(int64_t)pend * MMC_REC + tid] = v;
+        myrec[(int64_t)pend * MMC_RSTRIDE + tid] = v;
         if (tid < 9) {
             const int a = tid / 3, d = tid % 3;
             (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + 3 * pend + a] = v;
@@ -415,7 +419,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
             v.x = pd_word(2 * piece);
             v.y = pd_word(2 * piece + 1);
         } else {
-            v = *reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC + 2 * piece);
+            v = *reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_RSTRIDE + 2 * piece);
         }
         return v;
     };
@@ -614,5 +618,5 @@ __global__ void k_settle_rec(BatchView bv, double *rec, const MoveRec *prev,
         return;
     const int m = prev[r].mol - 1;
     const double v = (t < 9) ? prev[r].atoms_new[t] : prev[r].com_new[t - 9];
-    rec[((int64_t)r * bv.n_mol + m) * MMC_REC + t] = v;
+    rec[((int64_t)r * bv.n_mol + m) * MMC_RSTRIDE + t] = v;
 }

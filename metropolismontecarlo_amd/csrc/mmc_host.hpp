@@ -46,7 +46,7 @@ struct DeviceSystem {
     // fast paths (mmc_fast.hpp, mmc_total.hpp): systems whose molecules are all copies of one
     // 3-atom molecule get per-molecule records, launch constants and the erfc table
     bool homogeneous = false;
-    double *rec = nullptr;    // [R][n_mol][MMC_REC], only when homogeneous
+    double *rec = nullptr;    // [R][n_mol][MMC_RSTRIDE], only when homogeneous
     FastConsts fc{};          // launch constants of the fast kernels
     double *qq_tab = nullptr; // [MMC_QQ_NINT][MMC_QQ_NCOEF] for the prepared kappa
     int32_t *kpack = nullptr; // [MMC_NK_STRIDE] packed k-vectors (k_pack_kvec)

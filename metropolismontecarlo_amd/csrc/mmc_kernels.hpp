@@ -379,7 +379,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
             *w = prev[r].atoms_new[tid - 3];
         }
         if (rec) // [atoms(9), com(3)] record of the molecule (mmc_fast.hpp)
-            rec[((int64_t)r * bv.n_mol + pend) * 12 + (tid < 3 ? 9 + tid : tid - 3)] = *w;
+            rec[((int64_t)r * bv.n_mol + pend) * 16 + (tid < 3 ? 9 + tid : tid - 3)] = *w;
     }
     __syncthreads();
 
@@ -454,7 +454,7 @@ struct SetMolArgs {
     double at[MMC_MAX_ATOMS][3];
 };
 
-// rec: the 12-double record array of homogeneous systems (mmc_fast.hpp) or NULL.
+// rec: the record array of homogeneous systems (12 doubles at a stride of 16, mmc_fast.hpp) or NULL.
 __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
 {
     const int t = threadIdx.x;
@@ -465,7 +465,7 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
         bv.ax[o] = a.at[t][0]; bv.ay[o] = a.at[t][1]; bv.az[o] = a.at[t][2];
     }
     if (rec && t < 12) {
-        double *o = rec + ((int64_t)a.r * bv.n_mol + a.i0) * 12;
+        double *o = rec + ((int64_t)a.r * bv.n_mol + a.i0) * 16;
         o[t] = t < 9 ? a.at[t / 3][t % 3] : a.com[t - 9];
     }
 }

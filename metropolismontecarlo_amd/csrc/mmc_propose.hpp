@@ -200,7 +200,7 @@ __global__ void k_propose(BatchView bv, const double *rec, MoveRec *ring, GenArg
         sub = true;
     }
     if (!sub && rec) {
-        const double *src = rec + ((int64_t)r * bv.n_mol + i0) * 12;
+        const double *src = rec + ((int64_t)r * bv.n_mol + i0) * 16; // MMC_RSTRIDE
         for (int q = 0; q < 9; q++) at[q] = src[q];
         for (int q = 0; q < 3; q++) com[q] = src[9 + q];
     } else if (!sub) {

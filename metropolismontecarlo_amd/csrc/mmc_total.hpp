@@ -52,15 +52,15 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_total_pairs(BatchView bv, const d
     const bool diag = ti_idx == tj_idx;
     const int i0 = ti_idx * MMC_TM, j0 = tj_idx * MMC_TM;
     const int ni = min(MMC_TM, n_mol - i0), nj = min(MMC_TM, n_mol - j0);
-    const double *myrec = rec + (int64_t)r * n_mol * MMC_REC;
+    const double *myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
 
-    // tiles are contiguous runs of records: straight 16-byte copies
+    // tiles are runs of consecutive records (96 of every 128 bytes): 16-byte copies
     for (int g = tid; g < ni * 6; g += MMC_BLOCK)
-        *reinterpret_cast<double2 *>(&sm.ti[2 * g]) =
-            *reinterpret_cast<const double2 *>(myrec + (int64_t)i0 * MMC_REC + 2 * g);
+        *reinterpret_cast<double2 *>(&sm.ti[2 * g]) = *reinterpret_cast<const double2 *>(
+            myrec + (int64_t)(i0 + g / 6) * MMC_RSTRIDE + 2 * (g % 6));
     for (int g = tid; g < nj * 6; g += MMC_BLOCK)
-        *reinterpret_cast<double2 *>(&sm.tj[2 * g]) =
-            *reinterpret_cast<const double2 *>(myrec + (int64_t)j0 * MMC_REC + 2 * g);
+        *reinterpret_cast<double2 *>(&sm.tj[2 * g]) = *reinterpret_cast<const double2 *>(
+            myrec + (int64_t)(j0 + g / 6) * MMC_RSTRIDE + 2 * (g % 6));
     for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += MMC_BLOCK)
         sm.qtab[k] = qq_tab[k];
     if (tid < 9) {
@@ -225,7 +225,7 @@ __global__ void k_rescale(BatchView bv, double *rec, double f)
         bv.ax[o] += d[0]; bv.ay[o] += d[1]; bv.az[o] += d[2];
     }
     if (rec) {
-        double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_REC;
+        double *o = rec + ((int64_t)r * bv.n_mol + j) * MMC_RSTRIDE;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const int64_t s = r * bv.atom_stride + fa + a;

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         const bool do_recip = (n_parts == 1) || (part == n_parts - 1);
         const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
         const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
-        double *const myrec = rec + (int64_t)r * n_mol * MMC_REC;
+        double *const myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
 
         // ---- the move record: one load instruction (lane t holds word t), then scalars ----
         const double *mvp = reinterpret_cast<const double *>(cur + r);
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             if (lane < 12)
                 sm.pvw[wv][lane] = pw;
             if (part == 0 && lane < 12) {
-                myrec[(int64_t)pend * MMC_REC + lane] = pw;
+                myrec[(int64_t)pend * MMC_RSTRIDE + lane] = pw;
                 if (lane < 9) {
                     const int a = lane / 3, d = lane % 3;
                     (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + 3 * pend + a] = pw;
@@ -142,11 +142,14 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             wave_sync();
         }
 
-        double a_lj0 = 0, a_lj1 = 0, a_v0 = 0, a_v1 = 0, a_q0 = 0, a_q1 = 0, a_rec = 0;
+        // The seven sums of the unit are reduced and parked in LDS (outw) by the phase that
+        // produces them, so no accumulator is live across phases.
+        double *const outw = sm.outw[wv];
         unsigned long long ovm0 = 0, ovm1 = 0; // lanes that saw an overlap, old / new state
 
         // ================= reciprocal part (ewalds.jl:718-826) =================
         if (do_recip) {
+            double a_rec = 0;
             // phase tables e^{i 2 pi k x / L}, k = -5..5, of the 3 moved atoms, old and new: 18 rows
             {
                 const int t = lane < 18 ? lane : 0;
@@ -194,11 +197,17 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 }
                 k = k2; kp = kp2; cf = cf2; so = so2;
             }
+            const double s6 = wave_sum(a_rec);
+            if (lane == 0)
+                outw[6] = s6;
             wave_sync(); // ptab is rewritten by this wave's next unit
+        } else if (lane == 0) {
+            outw[6] = 0.0;
         }
 
         // ================= pair part =================
         if (do_pairs) {
+            double a_lj0 = 0, a_lj1 = 0, a_v0 = 0, a_v1 = 0, a_q0 = 0, a_q1 = 0;
             // The chosen molecule stays in the register `w` (lane t = word t of the move record);
             // its coordinates are pulled into SGPRs with v_readlane where they are used, so only
             // the six doubles of the current atom a (both states) are live in the pair loop.
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                     const int ent = n < cnt ? list[n] : 0; // idle lanes: molecule 0, no gate bit
                     const int j = ent & ((1 << 27) - 1), f = (int)((unsigned)ent >> 27);
                     double t[MMC_REC];
-                    const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_REC);
+                    const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_RSTRIDE);
 #pragma unroll
                     for (int q = 0; q < 6; q++) {
                         const double2 v = src[q];
@@ -364,18 +373,20 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 if (cnt)
                     process(cnt);
             }
+            // wave reduction (fixed order: bitwise reproducible)
+            const double s0 = wave_sum(a_lj0), s1 = wave_sum(a_lj1), s2 = wave_sum(a_v0),
+                         s3 = wave_sum(a_v1), s4 = wave_sum(a_q0), s5 = wave_sum(a_q1);
+            if (lane == 0) {
+                outw[0] = s0; outw[1] = s1; outw[2] = s2; outw[3] = s3; outw[4] = s4; outw[5] = s5;
+            }
+        } else if (lane < 6) {
+            outw[lane] = 0.0;
         }
 
-        // ---- wave reduction (fixed order: bitwise reproducible) and the 64-byte result ----
-        const double s0 = wave_sum(a_lj0), s1 = wave_sum(a_lj1), s2 = wave_sum(a_v0),
-                     s3 = wave_sum(a_v1), s4 = wave_sum(a_q0), s5 = wave_sum(a_q1),
-                     s6 = wave_sum(a_rec);
-        const int o0 = ovm0 != 0ULL, o1 = ovm1 != 0ULL;
-        if (lane == 0) {
-            double *o = sm.outw[wv];
-            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = s4; o[5] = s5; o[6] = s6;
-            o[7] = pack_ovl(o0, o1, stamp, part_checksum(o, stamp));
-        }
+        // ---- the 64-byte result record ----
+        wave_sync();
+        if (lane == 0)
+            outw[7] = pack_ovl(ovm0 != 0ULL, ovm1 != 0ULL, stamp, part_checksum(outw, stamp));
         wave_sync();
         store_part(out + (int64_t)r * n_parts + part, sm.outw[wv], lane);
         wave_sync();
