@@ -15,12 +15,13 @@
 //     tile by 6 lanes x 16 B each ("LDS-staged neighbour tiles"), issued into registers and
 //     overlapped with the reciprocal-space arithmetic; the pair loops then read LDS only;
 //   * one lane per (neighbour, atom pair a-b): 9 lanes per neighbour, both states;
-//   * erfc(kappa r)/r comes from a piecewise degree-10 polynomial in r^2, 16 pieces per octave
+//   * erfc(kappa r)/r comes from a piecewise degree-9 polynomial in r^2, 16 pieces per octave
 //     over r^2 in [0.25, 256), selected by the exponent/mantissa bits of r^2: no sqrt, no
-//     division, no erfc in the loop.  The table (14 KB) is built once per kappa on the device
-//     from ocml erfc/sqrt at Chebyshev nodes; its error against exact arithmetic (<= 5e-15
-//     relative for kappa*r <= 4) is the conditioning error of erfc(kappa*sqrt(r2)) in fp64, i.e.
-//     the same as the reference's own direct evaluation (tests/test_gpu_table.py);
+//     division, no erfc in the loop.  The table (12.5 KB) is built once per kappa on the device
+//     from ocml erfc/sqrt at Chebyshev nodes; its error against exact arithmetic is <= 3e-15
+//     relative for kappa = 5.6/30 and <= 2e-14 up to kappa*r = 4 (tests/test_gpu_table.py) -- the
+//     conditioning error of erfc(kappa*sqrt(r2)) in fp64, which the reference's own direct
+//     evaluation carries too, is 5e-15 there;
 //   * LJ terms (only atom pairs with eps > 0.001, energy.jl:270) run as a second compacted pass;
 //   * move records are read from device memory (copied H2D on the stream), results are written
 //     straight to pinned host memory.
@@ -35,12 +36,12 @@
 #define MMC_RSTRIDE 16    // doubles between records in HBM: every record is one 128-byte line
                           // (at a 96-byte stride half of them straddled two lines and a gather
                           // fetched 1.5 lines per record)
-#define MMC_QQ_DEG 10
+#define MMC_QQ_DEG 9
 #define MMC_QQ_NCOEF (MMC_QQ_DEG + 1)
 #define MMC_QQ_NINT 160   // 10 octaves [2^-2, 2^8) x 16 sub-intervals
 #define MMC_QQ_UMIN 0.25
 #define MMC_QQ_UMAX 256.0    // the host selects this kernel only if r_cut^2 + 100 <= UMAX,
-#define MMC_QQ_XMAX 4.0      // kappa * sqrt(r_cut^2 + 100) <= XMAX (degree 10 is enough there)
+#define MMC_QQ_XMAX 4.0      // kappa * sqrt(r_cut^2 + 100) <= XMAX (degree 9 is enough there)
 #define MMC_QQ_KAPPA_MAX 0.5 // and kappa <= this (the series below UMIN needs kappa*r <= 0.25)
 #define MMC_FLIST_CAP 768
 #define MMC_PRE 3            // COM-scan iterations whose loads are issued at kernel entry: all of
@@ -66,6 +67,27 @@ struct FastConsts {
     double eps9[9], sig9[9];   // the LJ table by atom pair 3a + b (k_move_eval_wave)
 };
 
+// Horner in t over one piece's 10 coefficients, read as five 16-byte pairs: ds_read_b128 moves
+// twice the bytes per LDS cycle of the ds_read2_b64 an 8-byte aligned row gets (rows are 80 B, so
+// every row is 16-byte aligned, and 16 consecutive rows start in 16 different bank groups).
+__device__ __forceinline__ double qq_horner(const double *c, double t)
+{
+    static_assert(MMC_QQ_NCOEF == 10, "five coefficient pairs");
+    const double2 *c2 = reinterpret_cast<const double2 *>(c);
+    const double2 p4 = c2[4], p3 = c2[3], p2 = c2[2], p1 = c2[1], p0 = c2[0];
+    double acc = p4.y;
+    acc = fma(acc, t, p4.x);
+    acc = fma(acc, t, p3.y);
+    acc = fma(acc, t, p3.x);
+    acc = fma(acc, t, p2.y);
+    acc = fma(acc, t, p2.x);
+    acc = fma(acc, t, p1.y);
+    acc = fma(acc, t, p1.x);
+    acc = fma(acc, t, p0.y);
+    acc = fma(acc, t, p0.x);
+    return acc;
+}
+
 // f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t in [-1, 1).
 __device__ __forceinline__ double qq_table_eval(const double *tab, double u)
 {
@@ -73,13 +95,7 @@ __device__ __forceinline__ double qq_table_eval(const double *tab, double u)
     const int idx = (int)(bits >> 48) - 0x3FD0; // exponent + top 4 mantissa bits, 0 at u = 0.25
     const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
     const double d = __longlong_as_double(lo | 0x3FF0000000000000LL); // [1, 2): position in piece
-    const double t = 2.0 * d - 3.0;
-    const double *c = tab + idx * MMC_QQ_NCOEF;
-    double acc = c[MMC_QQ_DEG];
-#pragma unroll
-    for (int j = MMC_QQ_DEG - 1; j >= 0; j--)
-        acc = fma(acc, t, c[j]);
-    return acc;
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, 2.0 * d - 3.0);
 }
 
 // The same with the piece index clamped into the table: for predicated callers that evaluate
@@ -90,13 +106,7 @@ __device__ __forceinline__ double qq_table_eval_clamped(const double *tab, doubl
     const int idx = min(max((int)(bits >> 48) - 0x3FD0, 0), MMC_QQ_NINT - 1);
     const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
     const double d = __longlong_as_double(lo | 0x3FF0000000000000LL);
-    const double t = 2.0 * d - 3.0;
-    const double *c = tab + idx * MMC_QQ_NCOEF;
-    double acc = c[MMC_QQ_DEG];
-#pragma unroll
-    for (int j = MMC_QQ_DEG - 1; j >= 0; j--)
-        acc = fma(acc, t, c[j]);
-    return acc;
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, 2.0 * d - 3.0);
 }
 
 // u < UMIN happens only for like charges closer than 0.5 A (opposite charges that close are
@@ -231,7 +241,7 @@ struct FastShared {
     alignas(16) double tile[MMC_TILE * MMC_REC]; // neighbour records, written as double2
     alignas(16) double mvw[MV_WORDS + 1];        // this replica's move record
     alignas(16) double pvw[MV_WORDS + 1];        // its previous move record (pending commit)
-    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
     cplx ptab[2][3][3][MMC_NKTAB];
     double red[7 * MMC_WAVES];
     double qq9[9], ljp_eps[9], ljp_sig[9];

@@ -30,7 +30,7 @@ struct TotalPart {
 struct TotalShared {
     alignas(16) double ti[MMC_TM * MMC_REC]; // 6 KB each; ti doubles as reduction scratch
     alignas(16) double tj[MMC_TM * MMC_REC];
-    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
     double red[4];
     double qq9[9], ljp_eps[9], ljp_sig[9];
     uint16_t list[MMC_TM * MMC_TM];

@@ -30,7 +30,7 @@
 #define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
 
 struct WaveShared {
-    double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
     cplx ptab[WV_WAVES][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
     int32_t list[WV_WAVES][WV_LIST];
     alignas(16) double pvw[WV_WAVES][12];    // pending commit of the unit's replica, record layout
