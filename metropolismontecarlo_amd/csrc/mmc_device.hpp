@@ -73,13 +73,14 @@ struct PairAcc {
 // * The wrapped value d -+ box is fma(m, -box, d) with m = 0 or +-1 (m*box exact, one rounding,
 //   and d + 0*(-box) == d): no 64-bit select.  5 VALU (sub, cmp, bfi, cndmask, fma) instead of 12.
 struct BoxConsts {
-    double half, neg; // box/2 and -box, kept in registers across the pair loops
+    double half, neg, box; // box/2, -box and box, kept in registers across the pair loops
 };
 __device__ __forceinline__ BoxConsts box_consts(double box)
 {
     BoxConsts b;
     b.half = 0.5 * box;
     b.neg = -box;
+    b.box = box;
     return b;
 }
 __device__ __forceinline__ double vector1D(double c1, double c2, const BoxConsts &bc)
@@ -90,14 +91,16 @@ __device__ __forceinline__ double vector1D(double c1, double c2, const BoxConsts
     const double m = (fabs(d) < bc.half) ? 0.0 : copysign(1.0, d);
     return fma(m, bc.neg, d);
 }
-// |minimum image|, except that a wrapped component comes back as |d| - box (negative): its SQUARE
-// is bit for bit the square of vector1D's result, (|d| - L)^2 == (d -+ L)^2, which is all an r^2
-// needs.  4 VALU (sub, cmp |d|, cndmask, fma |d|) instead of 6.
+// The MAGNITUDE of the minimum image, for callers that only square it (an r^2):
+//     |vector1D(c1, c2)| == min(|d|, fl(box - |d|))     bit for bit,
+// because the reference keeps d when |d| < fl(box - |d|) and otherwise returns d -+ box, whose
+// magnitude is fl(box - |d|) (negation is exact; at a tie both candidates are the same number).
+// 3 VALU (sub, sub, min) instead of 6; a component beyond the box (|d| > box, atoms carried
+// outside by their molecule) gives box - |d| < 0, whose square is again the reference's.
 __device__ __forceinline__ double vector1D_abs(double c1, double c2, const BoxConsts &bc)
 {
     const double d = fabs(c2 - c1);
-    const double m = (d < bc.half) ? 0.0 : 1.0;
-    return fma(m, bc.neg, d);
+    return fmin(d, bc.box - d);
 }
 __device__ __forceinline__ double vector1D(double c1, double c2, double box)
 {

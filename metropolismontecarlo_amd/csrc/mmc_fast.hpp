@@ -88,25 +88,34 @@ __device__ __forceinline__ double qq_horner(const double *c, double t)
     return acc;
 }
 
-// f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t in [-1, 1).
+// piece index and position t in [-1, 1) inside the piece from the bits of u: the piece is the
+// exponent and the top 4 mantissa bits (0 at u = 0.25); the other 48 mantissa bits, shifted up by
+// 4, are the mantissa of d in [1, 2) and t = 2 d - 3.
+__device__ __forceinline__ double qq_piece(double u, int &idx)
+{
+    const unsigned lo = (unsigned)__double_as_longlong(u), hi = (unsigned)(__double_as_longlong(u) >> 32);
+    idx = (int)(hi >> 16) - 0x3FD0;
+    const unsigned dhi = (__builtin_amdgcn_alignbit(hi, lo, 28) & 0xFFFFFu) | 0x3FF00000u;
+    const double d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | (lo << 4)));
+    return fma(2.0, d, -3.0);
+}
+
+// f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t.
 __device__ __forceinline__ double qq_table_eval(const double *tab, double u)
 {
-    const long long bits = __double_as_longlong(u);
-    const int idx = (int)(bits >> 48) - 0x3FD0; // exponent + top 4 mantissa bits, 0 at u = 0.25
-    const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
-    const double d = __longlong_as_double(lo | 0x3FF0000000000000LL); // [1, 2): position in piece
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, 2.0 * d - 3.0);
+    int idx;
+    const double t = qq_piece(u, idx);
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
 }
 
 // The same with the piece index clamped into the table: for predicated callers that evaluate
 // every lane and discard what lies outside [UMIN, UMAX) afterwards.
 __device__ __forceinline__ double qq_table_eval_clamped(const double *tab, double u)
 {
-    const long long bits = __double_as_longlong(u);
-    const int idx = min(max((int)(bits >> 48) - 0x3FD0, 0), MMC_QQ_NINT - 1);
-    const long long lo = (bits & 0x0000FFFFFFFFFFFFLL) << 4;
-    const double d = __longlong_as_double(lo | 0x3FF0000000000000LL);
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, 2.0 * d - 3.0);
+    int idx;
+    const double t = qq_piece(u, idx);
+    idx = min(max(idx, 0), MMC_QQ_NINT - 1);
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
 }
 
 // u < UMIN happens only for like charges closer than 0.5 A (opposite charges that close are

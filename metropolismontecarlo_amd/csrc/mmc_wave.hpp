@@ -262,8 +262,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                         const bool in1 = g1 && !ov1 && (u1 < pp.qq_slack_sq);
                         double e0 = qq_table_eval_clamped(sm.qtab, u0);
                         double e1 = qq_table_eval_clamped(sm.qtab, u1);
-                        // like charges closer than 0.5 A: the series (practically never taken)
-                        if (__any((in0 && u0 < MMC_QQ_UMIN) || (in1 && u1 < MMC_QQ_UMIN))) {
+                        // like charges closer than sqrt(ovr): below r^2 = 0.25 the table ends and
+                        // the series takes over (practically never; tested with the compare the
+                        // overlap test has made anyway, UMIN <= ovr)
+                        if (__any(in0 && (u0 < pp.ovr)) || __any(in1 && (u1 < pp.ovr))) {
                             if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
                             if (u1 < MMC_QQ_UMIN) e1 = qq_pair_cold(u1, pp.kappa);
                         }
