@@ -10,7 +10,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmc_hip.so")
+# MMC_HIP_LIB: another build of the same library (A/B timing of kernel variants on one GPU box)
+LIB_PATH = os.environ.get("MMC_HIP_LIB") or os.path.join(_HERE, "libmmc_hip.so")
 
 MMC_OK, MMC_ERR_ARG, MMC_ERR_ASSERT, MMC_ERR_HIP, MMC_ERR_STATE, MMC_ERR_UNSUPPORTED = range(6)
 _STATUS_NAME = {1: "MMC_ERR_ARG", 2: "MMC_ERR_ASSERT", 3: "MMC_ERR_HIP", 4: "MMC_ERR_STATE",

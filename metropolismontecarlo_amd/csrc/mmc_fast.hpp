@@ -227,6 +227,7 @@ __global__ void k_build_rec(BatchView bv, double *rec, int r)
         o[3 * a] = bv.ax[a0 + a]; o[3 * a + 1] = bv.ay[a0 + a]; o[3 * a + 2] = bv.az[a0 + a];
     }
     o[9] = bv.comx[m0]; o[10] = bv.comy[m0]; o[11] = bv.comz[m0];
+    comf_store(bv, r, j, 0, o[9]); comf_store(bv, r, j, 1, o[10]); comf_store(bv, r, j, 2, o[11]);
 }
 
 // (per_replica = n_mol * MMC_RSTRIDE doubles)
@@ -236,6 +237,14 @@ __global__ void k_broadcast_rec(double *rec, int64_t per_replica)
     const int r = blockIdx.y + 1;
     if (i < per_replica)
         rec[r * per_replica + i] = rec[i];
+}
+
+__global__ void k_broadcast_f32(float *p, int64_t per_replica)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int r = blockIdx.y + 1;
+    if (i < per_replica)
+        p[r * per_replica + i] = p[i];
 }
 
 // k-vector constants packed for one load per k: kx | (ky+5) << 4 | (kz+5) << 8
@@ -347,6 +356,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
         } else {
             const int d = tid - 9;
             (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = v;
+            comf_store(bv, r, pend, d, v);
         }
     }
     if (do_recip && tid >= 64 && tid < 82) { // phase tables of the 3 moved atoms, old and new
@@ -638,4 +648,6 @@ __global__ void k_settle_rec(BatchView bv, double *rec, const MoveRec *prev,
     const int m = prev[r].mol - 1;
     const double v = (t < 9) ? prev[r].atoms_new[t] : prev[r].com_new[t - 9];
     rec[((int64_t)r * bv.n_mol + m) * MMC_RSTRIDE + t] = v;
+    if (t >= 9)
+        comf_store(bv, r, m, t - 9, v);
 }

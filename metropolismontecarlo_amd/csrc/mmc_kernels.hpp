@@ -28,7 +28,18 @@ struct BatchView {
     const int16_t *kmap; // [(nk+1)*(2nk+1)*(2nk+1)] -> k index or -1
     int32_t nkvecs, nk;
     double kappa, factor;
+    // single-precision copy of the centres of mass, SoA [R][3][cf_stride] (homogeneous systems
+    // only, else NULL): the prefilter stream of k_move_eval_wave's COM scan.  Every writer of a
+    // centre of mass keeps it in step through comf_store().
+    float *comf;
+    int64_t cf_stride;
 };
+
+__device__ __forceinline__ void comf_store(const BatchView &b, int r, int j, int d, double v)
+{
+    if (b.comf)
+        b.comf[((int64_t)r * 3 + d) * b.cf_stride + j] = (float)v;
+}
 
 __device__ __forceinline__ SysView sys_view(const BatchView &b, int r)
 {
@@ -380,6 +391,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
         }
         if (rec) // [atoms(9), com(3)] record of the molecule (mmc_fast.hpp)
             rec[((int64_t)r * bv.n_mol + pend) * 16 + (tid < 3 ? 9 + tid : tid - 3)] = *w;
+        if (tid < 3)
+            comf_store(bv, r, pend, tid, *w);
     }
     __syncthreads();
 
@@ -468,6 +481,8 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
         double *o = rec + ((int64_t)a.r * bv.n_mol + a.i0) * 16;
         o[t] = t < 9 ? a.at[t / 3][t % 3] : a.com[t - 9];
     }
+    if (t < 3)
+        comf_store(bv, a.r, a.i0, t, a.com[t]);
 }
 
 // Commit the outstanding proposal of every replica whose accept flag is set (main.jl:598-621),

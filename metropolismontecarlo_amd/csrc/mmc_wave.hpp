@@ -27,7 +27,8 @@
 #include "mmc_fast.hpp"
 
 #define WV_WAVES 4   // waves (= units in flight) per workgroup
-#define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
+#define WV_LIST 512  // neighbour-list slots per wave; the scan flushes when fewer than 64 WV_PF are free
+#define WV_PF 6      // 64-molecule blocks of the COM scan in flight ahead of the one being tested
 
 struct WaveShared {
     alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
@@ -36,6 +37,22 @@ struct WaveShared {
     alignas(16) double pvw[WV_WAVES][12];    // pending commit of the unit's replica, record layout
     alignas(16) double outw[WV_WAVES][8];    // the PartOut being assembled
 };
+
+// Diagnostic build (-DWV_STAMPS, scripts/stamps.sh): lane 0 of every unit records the shader clock
+// at the boundaries of its phases into a device array the host reads back (mmc_debug_stamps).
+// Compiled out of the product: the stamps and their s_waitcnt would slow what they measure.
+#ifdef WV_STAMPS
+#define WV_NSTAMP 8
+__device__ unsigned long long g_wv_stamps[65536 * WV_NSTAMP];
+#define WV_STAMP(i)                                                                              \
+    do {                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+        if (lane == 0 && unit < 65536)                                                           \
+            g_wv_stamps[unit * WV_NSTAMP + (i)] = __builtin_amdgcn_s_memtime();                  \
+    } while (0)
+#else
+#define WV_STAMP(i)
+#endif
 
 // Orders this wave's own LDS traffic (a wave's DS instructions execute in order; this only stops
 // the compiler from moving accesses across the point).
@@ -58,6 +75,59 @@ __device__ __forceinline__ double lane_f64(double v, int src)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, src);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), src);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// sin and cos of a moderate angle (here 2 pi c / L with c within a few box lengths): quadrant
+// reduction by a two-part pi/2 (Cody-Waite: n * pio2_1 is exact for n < 2^20, so the reduction
+// holds its 1e-16 absolute accuracy up to |x| ~ 8e5) and the fdlibm kernel polynomials on
+// |r| <= pi/4 (< 1 ulp each) -- the accuracy class of the libm sin/cos the reference calls, in
+// ~45 instructions and 16 registers instead of ocml's ~200 / 60 (whose Payne-Hanek path for huge
+// arguments is what costs).  An atom more than 1e5 box lengths outside its box is first folded
+// back by whole periods, at the accuracy such a coordinate has left.
+__device__ __forceinline__ void sincos_moderate(double x, double &sn, double &cs)
+{
+    if (!(fabs(x) < 8.0e5))
+        x = fma(-6.283185307179586, rint(x * 0.15915494309189535), x);
+    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
+    double r = fma(-fn, 1.57079632673412561417e+00, x);              // pio2_1 (33 bits)
+    r = fma(-fn, 6.07710050650619224932e-11, r);                     // pio2_1t
+    const int n = (int)fn;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;                           // S6
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);                     // S1
+    const double s = fma(z * r, ps, r);
+    double pc = -1.13596475577881948265e-11;                          // C6
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);                      // C1
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+
+// phase_row (mmc_device.hpp) on sincos_moderate: the recurrence of ewalds.jl:564-585 unchanged.
+__device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row /* [MMC_NKTAB] */)
+{
+    double sn, cs;
+    sincos_moderate(MMC_TWOPI * x / L, sn, cs);
+    const cplx e1 = { cs, sn }, one = { 1.0, 0.0 };
+    row[5] = one;
+    row[6] = e1;
+    row[4] = c_conj(e1);
+    cplx p = e1;
+#pragma unroll
+    for (int k = 2; k <= 5; k++) {
+        p = c_mul(p, e1);
+        row[5 + k] = p;
+        row[5 - k] = c_conj(p);
+    }
 }
 
 // grid: any number of workgroups of WV_WAVES waves; wave w of workgroup g handles units
@@ -84,6 +154,11 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
     const int np = (n_parts == 1) ? 1 : n_parts - 1;
     const int plen = (n_mol + np - 1) / np;
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
+    // Prefilter threshold.  With c^ = fl32(c): |d^ - d| <= 3 eps L, the fp32 minimum image adds
+    // 2 eps L, so every component is off by at most 5 eps L (eps = 2^-24, |c| <= L), r^2 by at
+    // most 3 L * 5 eps L plus 3 eps L^2 of fp32 rounding = 18 eps L^2; 32 eps L^2 is used.
+    const float boxf = (float)box;
+    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
     int32_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
 
@@ -105,11 +180,13 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
         double *const myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
 
+        WV_STAMP(0); // unit start
         // ---- the move record: one load instruction (lane t holds word t), then scalars ----
         const double *mvp = reinterpret_cast<const double *>(cur + r);
         double w = 0.0;
         if (lane < MV_WORDS)
             w = mvp[lane];
+        WV_STAMP(1); // move record arrived
         const int gflag = flagv ? __builtin_amdgcn_readfirstlane((int)flagv[r]) : -1;
         const long long hdr = __double_as_longlong(w);
         const int i0 = lane_i32((int)hdr, 0) - 1;
@@ -137,6 +214,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 } else {
                     const int d = lane - 9;
                     (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = pw;
+                    comf_store(bv, r, pend, d, pw);
                 }
             }
             wave_sync();
@@ -156,9 +234,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 const int st = t / 9, q = t - 9 * st; // q = 3 l + d
                 const double x = __shfl(w, (st ? MV_AT_NEW : MV_AT_OLD) + q, 64);
                 if (lane < 18)
-                    phase_row(x, box, sm.ptab[wv][st][q / 3][q % 3]);
+                    phase_row_moderate(x, box, sm.ptab[wv][st][q / 3][q % 3]);
             }
             wave_sync();
+            WV_STAMP(2); // phase tables built
             const double *So = s_buf(bv, r, scur);
             double *Sn = s_buf(bv, r, scur ^ 1);
             const int n_it = (nkv + 63) >> 6;
@@ -200,6 +279,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             const double s6 = wave_sum(a_rec);
             if (lane == 0)
                 outw[6] = s6;
+            WV_STAMP(3); // reciprocal loop done
             wave_sync(); // ptab is rewritten by this wave's next unit
         } else if (lane == 0) {
             outw[6] = 0.0;
@@ -212,21 +292,22 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             // its coordinates are pulled into SGPRs with v_readlane where they are used, so only
             // the six doubles of the current atom a (both states) are live in the pair loop.
             double cc[2][3]; // centres of mass, st 0 = old, 1 = proposal
+            float ccf[2][3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
                 cc[0][d] = lane_f64(w, MV_COM_OLD + d);
                 cc[1][d] = lane_f64(w, MV_COM_NEW + d);
+                ccf[0][d] = (float)cc[0][d];
+                ccf[1][d] = (float)cc[1][d];
             }
-            const double *comx = bv.comx + r * bv.mol_stride, *comy = bv.comy + r * bv.mol_stride,
-                         *comz = bv.comz + r * bv.mol_stride;
 
             // ---- neighbours list[0 .. cnt): lane n takes neighbour n0 + n ----
             auto process = [&](int cnt) {
                 wave_sync();
                 for (int n0 = 0; n0 < cnt; n0 += 64) {
                     const int n = n0 + lane;
-                    const int ent = n < cnt ? list[n] : 0; // idle lanes: molecule 0, no gate bit
-                    const int j = ent & ((1 << 27) - 1), f = (int)((unsigned)ent >> 27);
+                    const bool act = n < cnt;
+                    const int j = act ? list[n] : 0; // idle lanes: molecule 0, gates forced off
                     double t[MMC_REC];
                     const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_RSTRIDE);
 #pragma unroll
@@ -235,13 +316,27 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                         t[2 * q] = v.x;
                         t[2 * q + 1] = v.y;
                     }
+                    if (n0 == 0)
+                        WV_STAMP(5); // first neighbour records arrived
                     if (j == pend) {
 #pragma unroll
                         for (int q = 0; q < MMC_REC; q++)
                             t[q] = pvw[q];
                     }
-                    const bool g0 = (f & 4) != 0, g1 = (f & 8) != 0; // ewalds.jl:340 per state
-                    const bool l0 = (f & 1) != 0, l1 = (f & 2) != 0; // energy.jl:254 per state
+                    // the gates, exactly: COM minimum image of both states on the reference's
+                    // arithmetic (energy.jl:248-254, ewalds.jl:334-340)
+                    bool g0, g1, l0, l1;
+                    {
+                        const double x0 = vector1D_abs(cc[0][0], t[9], bc), y0 = vector1D_abs(cc[0][1], t[10], bc),
+                                     z0 = vector1D_abs(cc[0][2], t[11], bc);
+                        const double x1 = vector1D_abs(cc[1][0], t[9], bc), y1 = vector1D_abs(cc[1][1], t[10], bc),
+                                     z1 = vector1D_abs(cc[1][2], t[11], bc);
+                        const double c0 = x0 * x0 + y0 * y0 + z0 * z0, c1 = x1 * x1 + y1 * y1 + z1 * z1;
+                        g0 = act && (c0 < pp.qq_gate_sq); // ewalds.jl:340
+                        g1 = act && (c1 < pp.qq_gate_sq);
+                        l0 = same_gate ? g0 : (act && (c0 < pp.lj_gate_sq)); // energy.jl:254
+                        l1 = same_gate ? g1 : (act && (c1 < pp.lj_gate_sq));
+                    }
                     // one atom pair (a, b), both states.  The Coulomb term needs only r^2, and
                     // (|d| - L)^2 == (d -+ L)^2 bit for bit, so the minimum image is taken on
                     // |d| (4 instructions per component instead of 6); the signed vector is
@@ -325,56 +420,61 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 wave_sync();
             };
 
-            // ---- COM gates of both states (energy.jl:248-254, ewalds.jl:334-340): lane per
-            // molecule, survivors appended to the list in ascending j; two 64-molecule blocks of
-            // centres of mass are always in flight ahead of the one being tested ----
+            // ---- COM scan, single-precision prefilter of both states: lane per molecule,
+            // survivors appended to the list in ascending j.  WV_PF blocks of 64 molecules are in
+            // flight ahead of the one being tested (static registers: the body is unrolled WV_PF
+            // times and block b's registers are refilled as soon as it has been tested) ----
+            const float *cfx = bv.comf + (int64_t)r * 3 * bv.cf_stride, *cfy = cfx + bv.cf_stride,
+                        *cfz = cfy + bv.cf_stride;
             int base = j_begin;
             while (base < j_end) {
                 int cnt = 0;
-                double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
-                {
-                    const int ja = base + lane, jb = base + 64 + lane;
-                    if (ja < j_end) { ax = comx[ja]; ay = comy[ja]; az = comz[ja]; }
-                    if (jb < j_end) { bx = comx[jb]; by = comy[jb]; bz = comz[jb]; }
-                }
-                while (base < j_end && cnt <= WV_LIST - 64) {
-                    double cx = 0, cy = 0, cz = 0;
-                    const int jc = base + 128 + lane;
-                    if (jc < j_end) { cx = comx[jc]; cy = comy[jc]; cz = comz[jc]; }
-                    const int j = base + lane;
-                    if (pend >= base && pend < base + 64) { // uniform: at most one block per unit
-                        if (j == pend) { ax = pvw[9]; ay = pvw[10]; az = pvw[11]; }
-                    }
-                    int f = 0;
-                    {
-                        double r2[2];
+                float fx[WV_PF], fy[WV_PF], fz[WV_PF];
 #pragma unroll
-                        for (int st = 0; st < 2; st++) {
-                            const double dx = vector1D_abs(cc[st][0], ax, bc);
-                            const double dy = vector1D_abs(cc[st][1], ay, bc);
-                            const double dz = vector1D_abs(cc[st][2], az, bc);
-                            r2[st] = dx * dx + dy * dy + dz * dz;
-                        }
-                        if (same_gate) { // one cutoff for both terms (the reference's set-up)
-                            f = ((r2[0] < pp.lj_gate_sq) ? 5 : 0) | ((r2[1] < pp.lj_gate_sq) ? 10 : 0);
-                        } else {
-                            f = ((r2[0] < pp.lj_gate_sq) ? 1 : 0) | ((r2[1] < pp.lj_gate_sq) ? 2 : 0) // energy.jl:254
-                                | ((r2[0] < pp.qq_gate_sq) ? 4 : 0) | ((r2[1] < pp.qq_gate_sq) ? 8 : 0); // ewalds.jl:340
-                        }
-                        if (j >= j_end || j == i0)
-                            f = 0;
-                    }
-                    const unsigned long long m = __ballot(f != 0);
-                    if (f)
-                        list[cnt + lanes_below(m)] = j | (f << 27);
-                    cnt += __popcll(m);
-                    ax = bx; ay = by; az = bz;
-                    bx = cx; by = cy; bz = cz;
-                    base += 64;
+                for (int b = 0; b < WV_PF; b++) {
+                    const int j = base + 64 * b + lane;
+                    fx[b] = fy[b] = fz[b] = 0.f;
+                    if (j < j_end) { fx[b] = cfx[j]; fy[b] = cfy[j]; fz[b] = cfz[j]; }
                 }
+                while (base < j_end && cnt <= WV_LIST - 64 * WV_PF) {
+#pragma unroll
+                    for (int b = 0; b < WV_PF; b++) {
+                        if (base < j_end) { // uniform
+                            const int j = base + lane;
+                            float x = fx[b], y = fy[b], z = fz[b];
+                            {
+                                const int jn = base + 64 * WV_PF + lane; // refill this slot
+                                fx[b] = fy[b] = fz[b] = 0.f;
+                                if (jn < j_end) { fx[b] = cfx[jn]; fy[b] = cfy[jn]; fz[b] = cfz[jn]; }
+                            }
+                            if (pend >= base && pend < base + 64) { // uniform: one block per unit
+                                if (j == pend) { x = (float)pvw[9]; y = (float)pvw[10]; z = (float)pvw[11]; }
+                            }
+                            bool keep = false;
+#pragma unroll
+                            for (int st = 0; st < 2; st++) {
+                                float dx = fabsf(x - ccf[st][0]), dy = fabsf(y - ccf[st][1]),
+                                      dz = fabsf(z - ccf[st][2]);
+                                dx = fminf(dx, boxf - dx);
+                                dy = fminf(dy, boxf - dy);
+                                dz = fminf(dz, boxf - dz);
+                                const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                                keep = keep || (r2 < gatef);
+                            }
+                            keep = keep && (j < j_end) && (j != i0);
+                            const unsigned long long m = __ballot(keep);
+                            if (keep)
+                                list[cnt + lanes_below(m)] = j;
+                            cnt += __popcll(m);
+                            base += 64;
+                        }
+                    }
+                }
+                WV_STAMP(4); // scan done
                 if (cnt)
                     process(cnt);
             }
+            WV_STAMP(6); // pair loops done
             // wave reduction (fixed order: bitwise reproducible)
             const double s0 = wave_sum(a_lj0), s1 = wave_sum(a_lj1), s2 = wave_sum(a_v0),
                          s3 = wave_sum(a_v1), s4 = wave_sum(a_q0), s5 = wave_sum(a_q1);
@@ -392,5 +492,6 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         wave_sync();
         store_part(out + (int64_t)r * n_parts + part, sm.outw[wv], lane);
         wave_sync();
+        WV_STAMP(7); // result stored
     }
 }
