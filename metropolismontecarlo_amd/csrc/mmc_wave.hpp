@@ -27,7 +27,7 @@
 #include "mmc_fast.hpp"
 
 #define WV_WAVES 4   // waves (= units in flight) per workgroup
-#define WV_LIST 512  // neighbour-list slots per wave; the scan flushes when fewer than 64 WV_PF are free
+#define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
 #define WV_PF 6      // 64-molecule blocks of the COM scan in flight ahead of the one being tested
 
 struct WaveShared {
@@ -436,10 +436,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                     fx[b] = fy[b] = fz[b] = 0.f;
                     if (j < j_end) { fx[b] = cfx[j]; fy[b] = cfy[j]; fz[b] = cfz[j]; }
                 }
-                while (base < j_end && cnt <= WV_LIST - 64 * WV_PF) {
+                while (base < j_end && cnt <= WV_LIST - 64) {
 #pragma unroll
                     for (int b = 0; b < WV_PF; b++) {
-                        if (base < j_end) { // uniform
+                        if (base < j_end && cnt <= WV_LIST - 64) { // uniform
                             const int j = base + lane;
                             float x = fx[b], y = fy[b], z = fz[b];
                             {
