@@ -385,6 +385,11 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
 
     // ---- phase A: COM gates of both states, survivors compacted into sm.list (ascending j) ----
     auto scan_chunk = [&](int jb, bool prefetched) {
+        // A later chunk rewrites wcnt[] and the list: every wave must have read the previous
+        // chunk's counts first (with an empty first chunk and no reciprocal part there is no
+        // other barrier in between).
+        if (jb != j_begin)
+            __syncthreads();
         const int je = min(jb + MMC_FLIST_CAP, j_end);
         const int len = max(je - jb, 0);
         seg = ((len + MMC_WAVES * 64 - 1) / (MMC_WAVES * 64)) * 64;

@@ -102,17 +102,25 @@ def ReadNIST(filename):
     return xyz.copy(), qq_q, rm, xyz.copy(), tracker, box, names, atype
 
 
+def InitCubicGrid(n, rho):
+    """Ewald/initialConfigurations.jl:10-53 (= Monatomic/mainMonatomic.jl:85-125): n sites of the
+    smallest simple-cubic grid nCube^3 >= n (nCube >= 2) in a box of L = (n / rho)^(1/3), each at
+    (index + 0.01) * L / nCube, x running fastest.  Returns (L, r[n, 3])."""
+    L = (n / rho) ** (1.0 / 3.0)
+    nCube = 2
+    while nCube ** 3 < n:
+        nCube += 1
+    idx = np.arange(n)
+    posit = np.stack([idx % nCube, (idx // nCube) % nCube, idx // (nCube * nCube)], axis=1)
+    return L, (posit + 0.01) * (L / nCube)
+
+
 def cubic_lattice_water(n_mol, rho, geometry="spce", seed=11234):
     """Synthetic water box of the reference's crystal start (InitCubicGrid,
     initialConfigurations.jl:10-53: simple-cubic sites, offset 0.01 * spacing) with uniformly
     random orientations.  Used for the large synthetic configurations of BASELINE.json (cfg4/5).
     Returns (box, com[n_mol,3], coords[3 n_mol,3])."""
-    box = (n_mol / rho) ** (1.0 / 3.0)
-    nc = int(np.ceil(n_mol ** (1.0 / 3.0) - 1e-9))
-    d = box / nc
-    idx = np.arange(nc ** 3)[:n_mol]
-    ix, iy, iz = idx // (nc * nc), (idx // nc) % nc, idx % nc
-    com = (np.stack([ix, iy, iz], axis=1) + 0.01) * d
+    box, com = InitCubicGrid(n_mol, rho)
     if geometry == "spce":  # O-H 1.0 A, H-O-H 109.47 deg
         r_oh, ang = 1.0, np.deg2rad(109.47)
         masses = np.array([15.9994, 1.008, 1.008])

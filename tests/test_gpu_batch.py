@@ -532,3 +532,189 @@ def test_potential_ewald_record_array_equals_dict_list():
         for r in range(3):
             for key in ("energy", "virial", "coulomb", "lj", "real", "recip", "self", "n_overlap"):
                 assert arr[key][r] == dicts[r][key]
+
+
+# ---- the bench's own path at its own size, and the loops small systems never reach ----------------
+@pytest.mark.parametrize("kernel", [2, 1])
+def test_bench_path_750_molecules_device_moves(kernel, orc):
+    """What bench.py runs, under the parity gate: mmc_batch_run with device-side proposals
+    (k_propose + k_fetch_bytes), the per-move kernel with one part per move, NIST configuration 4
+    (750 molecules), two groups, more than two sweeps.  Running totals against a recompute
+    (Poly/main.jl:232-235) for every replica, and the final device state of two replicas against
+    the oracle's total energy of those coordinates."""
+    a = common.nist_arrays(4, "unwrapped")
+    n_mol, R = a["com"].shape[0], 64
+    n_steps = 2 * n_mol + 37
+    with make_batch(a, R) as b:
+        b.set_option("kernel", kernel)
+        b.set_option("device_moves", 1)
+        e0 = b.potential_ewald(as_array=True)["energy"].copy()
+        e1, st = b.run(n_steps, 298.15, 0.316555789, 0.05, seed=11234, energies=e0, n_groups=2,
+                       n_parts=1, n_threads=2)
+        assert st["moves"] == n_steps * R and st["launches"] == 2 * n_steps
+        assert st["torn_records"] == 0
+        acc = (st["trans_accept"] + st["rot_accept"]) / st["moves"]
+        assert 0.6 < acc < 0.9, acc                 # 0.756 in the bench's runs
+        S_inc = [b.get_replica(r)[2] for r in (0, R - 1)]
+        t1 = b.potential_ewald(as_array=True)
+        assert np.abs(e1 - t1["energy"]).max() < 1e-9 * np.abs(t1["energy"]).max()
+        assert len({round(x, 6) for x in e1}) == R  # every chain went its own way
+        for k, r in enumerate((0, R - 1)):
+            com, coords, S_new = b.get_replica(r)
+            assert np.abs(S_inc[k] - S_new).max() < 1e-9 * np.abs(S_new).max()
+            s = common.oracle_system(dict(a, com=com, coords=coords))
+            to = orc.potential_ewald(s, orc.Ewald(5.6 / s.box, 5, 27, s.box), RCUT, RCUT)
+            for key in ("energy", "lj", "real", "recip"):
+                assert rel(t1[key][r], to[key]) < TOL, (r, key)
+            assert (com >= 0).all() and (com <= a["box"]).all()
+            assert np.abs(com - a["com"]).max() > 0.05          # it moved
+
+
+def _dense_water(n_mol, seed=5):
+    from metropolismontecarlo_amd import io as mio
+    box, com, coords = mio.cubic_lattice_water(n_mol, 0.033101144, "spce", seed=seed)
+    a4 = common.nist_arrays(4, "unwrapped")
+    first = 3 * np.arange(n_mol, dtype=np.int64) + 1
+    return dict(com=com, coords=coords, first_atom=first, last_atom=first + 2,
+                atype=np.tile([1, 2, 2], n_mol).astype(np.int64),
+                charge=np.tile([mio.SPCE_Q_O, mio.SPCE_Q_H, mio.SPCE_Q_H], n_mol), eps=a4["eps"],
+                sig=a4["sig"], box=float(box))
+
+
+@pytest.mark.parametrize("kernel,parts", [(2, 1), (1, 1), (2, 3), (1, 2)])
+def test_long_neighbour_lists_and_many_molecules(kernel, parts, orc):
+    """1700 molecules with a 12.4 A cutoff: ~265 neighbours inside the gate, i.e. more than one
+    neighbour tile (150) and more than one molecule chunk (768) for the workgroup-per-move kernel,
+    and a neighbour list that overflows its 256 slots mid-scan for the wave-per-move kernel.
+    A chain of moves against the oracle and against the generic kernel, then a native-driver run
+    whose running total must match a recompute."""
+    from metropolismontecarlo_amd import structs
+    from metropolismontecarlo_amd.device import Batch
+    a = _dense_water(1700)
+    n_mol, rcut = 1700, 12.4
+    s_o = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
+    orc.recip_long(ew, s_o.coords, s_o.charge, s_o.box)
+    rng = np.random.default_rng(17)
+
+    def mk():
+        return Batch(2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+                     5.6 / a["box"], structs.factor, rcut, rcut)
+
+    with mk() as b, mk() as bg:
+        b.set_option("kernel", kernel)
+        b.set_option("parts", parts)
+        bg.set_option("kernel", 0)
+        bg.set_option("parts", 1)
+        b.recip_long()
+        bg.recip_long()
+        acc_prev = None
+        for step in range(6):
+            i = int(rng.integers(1, n_mol + 1)) if step != 3 else 1700   # the last molecule too
+            d = (rng.random(3) - 0.5) * 0.5
+            c_new = s_o.com[i - 1] + d
+            a_new = s_o.coords[3 * (i - 1):3 * i] + d
+            out, ov = b.eval(np.full(2, i), np.tile(c_new, (2, 1)), np.tile(a_new, (2, 1, 1)),
+                             accept_prev=acc_prev)
+            outg, ovg = bg.eval(np.full(2, i), np.tile(c_new, (2, 1)), np.tile(a_new, (2, 1, 1)),
+                                accept_prev=acc_prev)
+            do, ovo = orc.trial_move(i, s_o, ew, rcut, rcut, c_new, a_new)
+            scale = np.abs(do).max() + 1e4
+            assert bool(ov[0]) == ovo == bool(ovg[0])
+            assert np.abs(out[0] - do).max() < TOL * scale, (step, out[0], do)
+            assert np.abs(out[0] - outg[0]).max() < TOL * scale
+            assert np.array_equal(out[0], out[1])
+            accept = (step % 2 == 0) and not ovo
+            if accept:
+                s_o.com[i - 1] = c_new
+                s_o.coords[3 * (i - 1):3 * i] = a_new
+                ew.sumQExpOld[:] = ew.sumQExpNew
+            else:
+                ew.sumQExpNew[:] = ew.sumQExpOld
+            acc_prev = np.full(2, accept)
+        b.settle(acc_prev)
+        bg.settle(acc_prev)
+        for dev in (0, 1):
+            b.set_option("device_moves", dev)
+            e0 = b.potential_ewald(as_array=True)["energy"].copy()
+            e1, st = b.run(60, 298.15, 0.3, 0.05, seed=3, energies=e0, n_groups=1, n_parts=parts)
+            t1 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e1 - t1).max() < 1e-9 * np.abs(t1).max()
+            assert st["trans_accept"] + st["rot_accept"] > 0
+
+
+def test_config3_one_workgroup_per_move(orc):
+    """NIST configuration 3 (300 molecules in a 20 A box, ~157 neighbours): the second neighbour
+    tile of the workgroup-per-move kernel with the whole move in one workgroup.  Every proposal is
+    rejected, so each is evaluated from the initial state -- on all three kernels and the oracle."""
+    a = common.nist_arrays(3, "unwrapped")
+    g = common.golden(3, "unwrapped")
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    want = []
+    for mv in g["moves"][:4]:
+        do, ovo = orc.trial_move(mv["mol"], s, ew, RCUT, RCUT, np.array(mv["com_new"]),
+                                 np.array(mv["atoms_new"]))
+        ew.sumQExpNew[:] = ew.sumQExpOld
+        want.append((do, ovo))
+    for kernel in (0, 1, 2):
+        with make_batch(a, 2) as b:
+            b.set_option("kernel", kernel)
+            b.set_option("parts", 1)
+            b.recip_long()
+            for mv, (do, ovo) in zip(g["moves"][:4], want):
+                d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (2, 1)),
+                               np.tile(np.array(mv["atoms_new"]).ravel(), (2, 1)))
+                assert bool(ov[0]) == ovo
+                assert np.abs(d[0] - do).max() < TOL * (np.abs(do).max() + 1e4), (kernel, d[0], do)
+            b.settle([0, 0])
+
+
+# ---- the result hand-off: a record is consumed only if stamp and checksum agree -------------------
+def test_part_record_checksum_refuses_a_torn_record():
+    a = common.nist_arrays(1, "unwrapped")
+    mv = common.golden(1, "unwrapped")["moves"][0]
+    for kernel, parts in ((2, 1), (2, 3), (1, 2), (0, 1)):
+        with make_batch(a, 2) as b:
+            b.set_option("kernel", kernel)
+            b.set_option("parts", parts)
+            b.recip_long()
+            b.eval(mv["mol"], np.tile(mv["com_new"], (2, 1)),
+                   np.tile(np.array(mv["atoms_new"]).ravel(), (2, 1)))
+            for part in range(parts):
+                raw, stamp = b.peek_part(1, part)
+                assert len(raw) == 64 and b.part_validate(raw, stamp)
+                assert not b.part_validate(raw, stamp + 1)            # a stale launch's record
+                for piece in range(4):   # one 16-byte piece left over from another launch
+                    torn = bytearray(raw)
+                    for k in range(16):
+                        torn[16 * piece + k] ^= 0x5A if piece < 3 or k < 8 else 0
+                    if piece == 3:       # keep the stamp word, corrupt the recip sum next to it
+                        assert bytes(torn[56:64]) == raw[56:64]
+                    assert not b.part_validate(bytes(torn), stamp), (kernel, part, piece)
+                flipped = bytearray(raw)
+                flipped[20] ^= 1          # a single bit of one sum
+                assert not b.part_validate(bytes(flipped), stamp)
+            b.settle([0, 0])
+
+
+@pytest.mark.parametrize("device_moves", [1, 0])
+def test_driver_rereads_torn_records(device_moves):
+    """inject_torn: the driver's first N result copies are corrupted the way a torn PCIe write
+    would look (new stamp, one 16-byte piece stale).  It must refuse each of them, read again,
+    and arrive at exactly the chain an undisturbed run produces."""
+    a = common.nist_arrays(1, "unwrapped")
+    res = []
+    for inject in (0, 25):
+        with make_batch(a, 6) as b:
+            b.set_option("device_moves", device_moves)
+            b.recip_long()
+            if inject:
+                b.set_option("inject_torn", inject)
+            e, st = b.run(40, 298.15, 0.316555789, 0.05, seed=9, n_groups=2, n_threads=2)
+            res.append((e, st))
+    assert res[0][1]["torn_records"] == 0 and res[1][1]["torn_records"] == 25
+    assert np.array_equal(res[0][0], res[1][0])
+    for key in ("trans_accept", "rot_accept", "overlaps", "moves"):
+        assert res[0][1][key] == res[1][1][key]
