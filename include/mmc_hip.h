@@ -243,6 +243,23 @@ int32_t mmc_batch_qq_table(mmc_batch *b, const double *r2, int64_t n, double *ou
  * gr.jl's minimum image (:75-80), bin = ceil(r / dr), dr = box / 2 / numbins (:5,87), counted
  * when bin <= numbins.  hist[0 .. numbins] (numbins + 1 counters). */
 int32_t mmc_batch_rdf(mmc_batch *b, int32_t site, int32_t numbins, uint64_t *hist);
+/* The reference's own move generation for device-side proposals ("device_moves"): orientations are
+ * unit quaternions `totProps.quat[i]` and the atoms of a moved molecule are rebuilt from its
+ * body-fixed sites, ra[a] = COM + MATMUL(q_to_a(ei), db[a]) (Ewald/main.jl:516-549;
+ * quaternions.jl:11-50 q_to_a, :93-120 rotate_quaternion, :158-182 random_rotate_quaternion;
+ * auxillary.jl:154-159 MATMUL).  quat: [n_mol][4] (w, x, y, z), given to every replica; db: [3][3]
+ * body-fixed coordinates of the three sites.  mode 1 = q_to_a exactly as the reference has it,
+ * including its element (2,3) `2*(q[2]*q[4] + q[1]*q[2])` (quaternions.jl:43; the Allen & Tildesley
+ * original reads q[3]*q[4] + q[1]*q[2], so the reference's matrix is not orthogonal); mode 2 = the
+ * Allen & Tildesley matrix; mode 0 = back to the default (the current atoms are translated /
+ * rotated rigidly about the centre of mass, no quaternions kept).  A quaternion whose squared
+ * norm is off by more than 1e-6 returns MMC_ERR_ASSERT (the reference prints and exit()s,
+ * quaternions.jl:20-25).  An accepted move commits its quaternion (`totProps.quat[i] = ei`,
+ * main.jl:619).  The coordinates given at creation are the caller's: the reference builds them
+ * from the same quaternions (MakeAtomArrays, Ewald/setup.jl:447-537). */
+int32_t mmc_batch_set_orientations(mmc_batch *b, const double *quat, const double *db,
+                                   int32_t mode);
+int32_t mmc_batch_get_orientations(mmc_batch *b, int64_t r, double *quat);
 /* Result hand-off check (test hook): 1 if the 64-byte move-result record at `part_out_64` carries
  * launch stamp `stamp` and a matching checksum, else 0. */
 int32_t mmc_part_validate(const void *part_out_64, uint32_t stamp);

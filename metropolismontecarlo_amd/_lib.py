@@ -129,6 +129,8 @@ SIGNATURES = {
     "mmc_batch_set_option": [_vp, C.c_char_p, _i64],
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
+    "mmc_batch_set_orientations": [_vp, _dp, _dp, _i32],
+    "mmc_batch_get_orientations": [_vp, _i64, _dp],
     "mmc_part_validate": [_vp, C.c_uint32],
     "mmc_batch_peek_part": [_vp, _i64, _i32, _vp, C.POINTER(C.c_uint32)],
     "mmc_batch_rdf": [_vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)],

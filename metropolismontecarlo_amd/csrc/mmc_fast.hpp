@@ -53,7 +53,8 @@
 #define MV_AT_NEW 4
 #define MV_COM_OLD 13
 #define MV_AT_OLD 16
-#define MV_WORDS 25
+#define MV_Q_NEW 25
+#define MV_WORDS 29
 static_assert(sizeof(MoveRec) == MV_WORDS * 8, "MoveRec layout");
 static_assert(MMC_TILE * MMC_REC >= 7 * MMC_BLOCK, "the tile doubles as reduction scratch");
 
@@ -294,9 +295,9 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
     const BoxConsts bc = box_consts(box);
 
     // ================= trip 1: everything that depends on nothing =================
-    if (tid < MV_WORDS)
+    if (tid < MV_Q_NEW)
         sm.mvw[tid] = reinterpret_cast<const double *>(cur + r)[tid];
-    else if (prev && tid >= 32 && tid < 32 + MV_WORDS)
+    else if (prev && tid >= 32 && tid < 32 + MV_Q_NEW)
         sm.pvw[tid - 32] = reinterpret_cast<const double *>(prev + r)[tid - 32];
     else if (tid == 63)
         sm.gflag = flagv ? (int)flagv[r] : -1; // device-generated records: flags travel apart
@@ -359,6 +360,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
             comf_store(bv, r, pend, d, v);
         }
     }
+    if (part == 0 && commit && tid >= 12 && tid < 16)
+        quat_commit(bv, r, pend, tid - 12, prev[r].q_new[tid - 12], quat_valid(prev[r].q_new));
     if (do_recip && tid >= 64 && tid < 82) { // phase tables of the 3 moved atoms, old and new
         const int t = tid - 64;
         const int st = t / 9, l = (t % 9) / 3, d = t % 3;

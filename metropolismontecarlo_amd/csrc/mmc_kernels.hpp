@@ -33,6 +33,10 @@ struct BatchView {
     // centre of mass keeps it in step through comf_store().
     float *comf;
     int64_t cf_stride;
+    // orientation quaternions [R][n_mol][4] (totProps.quat, Ewald/main.jl:527,535,619) or NULL:
+    // only kept when the caller asked for the reference's quaternion move generation
+    // (mmc_batch_set_orientations); committed together with the coordinates of an accepted move
+    double *quat;
 };
 
 __device__ __forceinline__ void comf_store(const BatchView &b, int r, int j, int d, double v)
@@ -271,7 +275,21 @@ struct MoveRec {
     double atoms_new[9];
     double com_old[3];
     double atoms_old[9];
+    double q_new[4]; // proposed orientation `ei` (main.jl:528,532) when quaternions are kept
+                     // (k_propose), else zeros: a record with |q_new| = 0 commits no quaternion
 };
+
+// commit `totProps.quat[i] = ei` (main.jl:619): lane t in [0, 4) writes component t
+__device__ __forceinline__ void quat_commit(const BatchView &b, int r, int mol0, int t, double v,
+                                            bool valid)
+{
+    if (b.quat && valid)
+        b.quat[((int64_t)r * b.n_mol + mol0) * 4 + t] = v;
+}
+__device__ __forceinline__ bool quat_valid(const double *q)
+{
+    return q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3] > 0.25;
+}
 
 struct PartOut {
     double lj_pot[2], lj_vir[2], qq_pot[2]; // [old, new] raw sums of this workgroup's j-range
@@ -394,6 +412,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
         if (tid < 3)
             comf_store(bv, r, pend, tid, *w);
     }
+    if (part == 0 && commit && tid >= 12 && tid < 16)
+        quat_commit(bv, r, pend, tid - 12, prev[r].q_new[tid - 12], quat_valid(prev[r].q_new));
     __syncthreads();
 
     const bool do_pairs = (n_parts == 1) || (part < n_parts - 1);
@@ -490,9 +510,13 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
 __global__ void k_settle(BatchView bv, const MoveRec *prev, const int32_t *accept, int r_base)
 {
     const int r = r_base + blockIdx.x, t = threadIdx.x;
-    if (!accept[r] || t >= 12)
+    if (!accept[r] || t >= 16)
         return;
     const int m = prev[r].mol - 1;
+    if (t >= 12) {
+        quat_commit(bv, r, m, t - 12, prev[r].q_new[t - 12], quat_valid(prev[r].q_new));
+        return;
+    }
     if (t < 3) {
         (t == 0 ? bv.comx : t == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + m] =
             prev[r].com_new[t];

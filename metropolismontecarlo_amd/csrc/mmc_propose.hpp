@@ -147,6 +147,46 @@ __device__ inline void apply_xform(const MoveXform &x, const double *com, const 
     }
 }
 
+// ---- the reference's own move generation: quaternions + body-fixed sites -------------------------
+// (selected by mmc_batch_set_orientations; Ewald/main.jl:516-549)
+//   q_to_a              quaternions.jl:11-50.  `faithful`: element (2,3) as the reference has it,
+//                       2*(q2*q4 + q1*q2) -- a typo for 2*(q3*q4 + q1*q2), SURVEY quirk Q12, which
+//                       makes the matrix non-orthogonal; !faithful: the Allen & Tildesley matrix.
+//   quatmul             quaternions.jl:76-91
+//   rotate_quaternion   quaternions.jl:93-120   rot = (cos(angle/2), sin(angle/2) * axis), rot * old
+//   MATMUL              auxillary.jl:154-159    (dot(db, a[:,1]), dot(db, a[:,2]), dot(db, a[:,3]))
+__host__ __device__ inline void mmc_q_to_a(const double *q, int faithful, double a[3][3])
+{
+    const double q1 = q[0], q2 = q[1], q3 = q[2], q4 = q[3];
+    a[0][0] = q1 * q1 + q2 * q2 - q3 * q3 - q4 * q4;
+    a[0][1] = 2 * (q2 * q3 + q1 * q4);
+    a[0][2] = 2 * (q2 * q4 - q1 * q3);
+    a[1][0] = 2 * (q2 * q3 - q1 * q4);
+    a[1][1] = q1 * q1 - q2 * q2 + q3 * q3 - q4 * q4;
+    a[1][2] = faithful ? 2 * (q2 * q4 + q1 * q2) : 2 * (q3 * q4 + q1 * q2);
+    a[2][0] = 2 * (q2 * q4 + q1 * q3);
+    a[2][1] = 2 * (q3 * q4 - q1 * q2);
+    a[2][2] = q1 * q1 - q2 * q2 - q3 * q3 + q4 * q4;
+}
+
+__host__ __device__ inline void mmc_quatmul(const double *a, const double *b, double *c)
+{
+    c[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    c[1] = a[1] * b[0] + a[0] * b[1] - a[3] * b[2] + a[2] * b[3];
+    c[2] = a[2] * b[0] + a[3] * b[1] + a[0] * b[2] - a[1] * b[3];
+    c[3] = a[3] * b[0] - a[2] * b[1] + a[1] * b[2] + a[0] * b[3];
+}
+
+// ra[a] = COM + MATMUL(ai, db[a]) for the three sites (main.jl:543-549)
+__host__ __device__ inline void mmc_space_fixed(const double *com, const double a[3][3],
+                                                const double *db /* [3][3] */, double *at_new)
+{
+    for (int s = 0; s < 3; s++)
+        for (int k = 0; k < 3; k++)
+            at_new[3 * s + k] = com[k] + (db[3 * s] * a[0][k] + db[3 * s + 1] * a[1][k]
+                                          + db[3 * s + 2] * a[2][k]);
+}
+
 // n bytes from mapped pinned host memory into device memory (the per-step flag bytes).
 __global__ void k_fetch_bytes(uint8_t *dst, const uint8_t *src, int n)
 {
@@ -169,6 +209,9 @@ struct GenArgs {
     int ring;             // slots of the record ring; step s lives in slot s % ring
     int64_t ring_stride;  // records per slot (= replicas of the batch)
     const uint8_t *flag0; // [R] flag byte of step0 (only consulted when n_mol == 1, see below)
+    int quat_mode;        // 0: rigid transformation of the current atoms; 1 / 2: the reference's
+                          // quaternion route with the faithful / the Allen-Tildesley q_to_a
+    double db[9];         // body-fixed sites db[a] of the molecule (quat_mode != 0)
 };
 
 // One thread per (replica, step): read the chosen molecule's current state, draw the move and
@@ -217,9 +260,51 @@ __global__ void k_propose(BatchView bv, const double *rec, MoveRec *ring, GenArg
     for (int q = 0; q < 3; q++) m.com_old[q] = com[q];
     for (int q = 0; q < 9; q++) m.atoms_old[q] = at[q];
     const ChainKey ck{ ga.seed, (uint32_t)(ga.replica0 + (uint64_t)r) };
-    const MoveXform x = propose_xform(ck, (uint64_t)(ga.rng_off + step), bv.box, sz.x, sz.y, com);
-    for (int q = 0; q < 3; q++) m.com_new[q] = x.com_new[q];
-    for (int a = 0; a < 3; a++)
-        apply_xform(x, com, &at[3 * a], &m.atoms_new[3 * a]);
+    const uint64_t rs = (uint64_t)(ga.rng_off + step);
+    if (ga.quat_mode && bv.quat) {
+        // the reference's route (main.jl:516-549): the orientation is a quaternion, the atoms are
+        // rebuilt from the body-fixed sites on every move
+        double q_old[4], q_new[4], A[3][3];
+        const double *qsrc = bv.quat + ((int64_t)r * bv.n_mol + i0) * 4;
+        if (sub) {
+            const MoveRec *prev = ring + (int64_t)((step + ga.ring - 1) % ga.ring) * ga.ring_stride + r;
+            if (quat_valid(prev->q_new))
+                qsrc = prev->q_new;
+        }
+        for (int q = 0; q < 4; q++) q_old[q] = qsrc[q];
+        const Uniform2 u0 = mmc_draw(ck, rs, MMC_SLOT_KIND);
+        const Uniform2 u1 = mmc_draw(ck, rs, MMC_SLOT_MOVE);
+        if (u0.a < 0.5) { // translation: random_translate_vector + PBC, ei = quat[i] (:519-528)
+            const double zeta[3] = { u0.b - 0.5, u1.a - 0.5, u1.b - 0.5 };
+            for (int k = 0; k < 3; k++) m.com_new[k] = pbc_wrap(com[k] + zeta[k] * sz.x, bv.box);
+            for (int q = 0; q < 4; q++) q_new[q] = q_old[q];
+        } else {          // rotation: random_rotate_quaternion (:529-536)
+            double e[3], norm;
+            uint32_t slot = MMC_SLOT_AXIS;
+            do { // random_vector (quaternions.jl:52-74)
+                const Uniform2 p = mmc_draw(ck, rs, slot), q = mmc_draw(ck, rs, slot + 1);
+                slot += 2;
+                e[0] = 2.0 * p.a - 1.0; e[1] = 2.0 * p.b - 1.0; e[2] = 2.0 * q.a - 1.0;
+                norm = e[0] * e[0] + e[1] * e[1] + e[2] * e[2];
+            } while (!(norm < 1.0) || norm == 0.0);
+            const double sq = sqrt(norm);
+            for (int k = 0; k < 3; k++) e[k] = e[k] / sq;           // e ./ sqrt(norm)
+            const double angle = (2.0 * u1.a - 1.0) * sz.y;          // quaternions.jl:176
+            double sh, ch;
+            sincos(0.5 * angle, &sh, &ch);
+            const double rot[4] = { ch, sh * e[0], sh * e[1], sh * e[2] }; // :113-114
+            mmc_quatmul(rot, q_old, q_new);                          // :116
+            for (int k = 0; k < 3; k++) m.com_new[k] = com[k];
+        }
+        mmc_q_to_a(q_new, ga.quat_mode == 1, A);
+        mmc_space_fixed(m.com_new, A, ga.db, m.atoms_new);
+        for (int q = 0; q < 4; q++) m.q_new[q] = q_new[q];
+    } else {
+        const MoveXform x = propose_xform(ck, rs, bv.box, sz.x, sz.y, com);
+        for (int q = 0; q < 3; q++) m.com_new[q] = x.com_new[q];
+        for (int a = 0; a < 3; a++)
+            apply_xform(x, com, &at[3 * a], &m.atoms_new[3 * a]);
+        for (int q = 0; q < 4; q++) m.q_new[q] = 0.0;
+    }
     *cur = m;
 }

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         // ---- the move record: one load instruction (lane t holds word t), then scalars ----
         const double *mvp = reinterpret_cast<const double *>(cur + r);
         double w = 0.0;
-        if (lane < MV_WORDS)
+        if (lane < MV_Q_NEW)
             w = mvp[lane];
         WV_STAMP(1); // move record arrived
         const int gflag = flagv ? __builtin_amdgcn_readfirstlane((int)flagv[r]) : -1;
@@ -203,6 +203,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             if (lane < 9) pw = pvp[MV_AT_NEW + lane];
             else if (lane < 12) pw = pvp[MV_COM_NEW + lane - 9];
             else if (lane == 12) pw = pvp[0];
+            else if (lane < 17) pw = pvp[MV_Q_NEW + lane - 13];
             pend = lane_i32((int)__double_as_longlong(pw), 12) - 1;
             if (lane < 12)
                 sm.pvw[wv][lane] = pw;
@@ -216,6 +217,12 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                     (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = pw;
                     comf_store(bv, r, pend, d, pw);
                 }
+            }
+            if (bv.quat) { // totProps.quat[i] = ei (main.jl:619)
+                const double q0 = __shfl(pw, 13, 64), q1 = __shfl(pw, 14, 64),
+                             q2 = __shfl(pw, 15, 64), q3 = __shfl(pw, 16, 64);
+                if (part == 0 && lane >= 13 && lane < 17)
+                    quat_commit(bv, r, pend, lane - 13, pw, q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 > 0.25);
             }
             wave_sync();
         }

@@ -346,6 +346,21 @@ class Batch:
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
         return e, st.asdict()
 
+    def set_orientations(self, quat, db, faithful=True):
+        """Turn on the reference's quaternion move generation for device-side proposals
+        (mmc_batch_set_orientations): quat (n_mol, 4), db (3, 3) body-fixed sites; faithful keeps
+        the reference's q_to_a including its (2,3) element.  quat=None turns it off."""
+        if quat is None:
+            check(self._L.mmc_batch_set_orientations(self._h, None, None, 0))
+            return
+        q, d = _f64(quat).reshape(self.n_mol, 4), _f64(db).reshape(3, 3)
+        check(self._L.mmc_batch_set_orientations(self._h, _d(q), _d(d), 1 if faithful else 2))
+
+    def get_orientations(self, r):
+        q = np.empty((self.n_mol, 4))
+        check(self._L.mmc_batch_get_orientations(self._h, int(r), _d(q)))
+        return q
+
     def peek_part(self, r, part):
         """(64 raw bytes, stamp) of the result record of (replica r, part) of the last eval()."""
         buf = (C.c_uint8 * 64)()
