@@ -220,8 +220,9 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
 /* Tuning switches (no effect on results beyond summation order):
  *   "parts"            as mmc_batch_set_parts
  *   "kernel"           2 = one wavefront per trial move, persistent workgroups, erfc(kappa r)/r
- *                      table (default when every molecule has the same atom types and charges),
- *                      1 = one workgroup per trial move (LDS-tiled, same table), 0 = generic
+ *                      table; 1 = one workgroup per trial move (LDS-tiled, same table);
+ *                      3 = 2 for launches of at least 16 moves per compute unit, else 1 (default
+ *                      when every molecule has the same atom types and charges); 0 = generic
  *   "wave_wgs"         workgroups of a kernel-2 launch (0 = 4 per compute unit)
  *   "inject_torn"      N > 0: the native driver corrupts its first N copies of result records
  *                      before checking them, as a torn PCIe write would (test hook: the check must

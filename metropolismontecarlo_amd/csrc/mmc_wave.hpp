@@ -502,3 +502,225 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         WV_STAMP(7); // result stored
     }
 }
+
+// =================================================================================================
+// k_total_wave -- the pair part of potential(..., "ewald") (Ewald/energy.jl:972-1001) on the same
+// scheme as k_move_eval_wave: a wave per unit, lane per neighbour, the chosen molecule in scalar
+// registers, fp32 prefilter + exact fp64 gate, erfc table.
+//
+// Every molecule pair is visited once (i < j; see mmc_total.hpp for why that equals the
+// reference's "twice, then halve" up to summation order, and how the overlap sentinel is kept).
+// Unit u of a replica takes molecules u and n_mol - 1 - u: molecule i scans j > i, so pairing the
+// two ends gives every unit the same scan length.  Per replica ceil(n_mol / 2) partial sums are
+// written; k_total_reduce adds them in index order.
+//
+// Against k_total_pairs (64 x 64 tiles): 2.7 k VALU instructions in each of 4 waves per tile pair
+// and 713 KB of HBM traffic per evaluation (every tile re-read by 12 workgroups) become ~1.3 k per
+// wave-unit and one gather per neighbour (profiles/README.md, round 2).
+struct TotalWaveShared {
+    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    int32_t list[WV_WAVES][WV_LIST];
+};
+
+#define WV_TOTAL_WAVES_PER_SIMD 5 // 87 VGPRs: the single-state pair loop needs fewer than the move kernel
+__global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_total_wave(
+    BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
+    PairParams pp, TotalPart *out, int units_per_rep, int n_units)
+{
+    __shared__ __align__(16) TotalWaveShared sm;
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += WV_WAVES * 64)
+        sm.qtab[k] = qq_tab[k];
+    __syncthreads();
+
+    const int n_mol = bv.n_mol;
+    const double box = bv.box;
+    const BoxConsts bc = box_consts(box);
+    const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
+    const float boxf = (float)box;
+    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
+    int32_t *const list = sm.list[wv];
+
+    for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane)); // see k_move_eval_wave
+        const int r = unit / units_per_rep, u = unit - r * units_per_rep;
+        const double *myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
+        const float *cfx = bv.comf + (int64_t)r * 3 * bv.cf_stride, *cfy = cfx + bv.cf_stride,
+                    *cfz = cfy + bv.cf_stride;
+        double a_lj = 0, a_v = 0, a_q = 0;
+        unsigned long long ovm = 0;
+
+        // The unit's two molecules as lane-distributed records (lane t = word t); the neighbours
+        // of both go into ONE list, tagged with the molecule they belong to, so that the pair
+        // loop runs on full batches whatever the split between the two (molecule u has nearly all
+        // of its neighbours above it, molecule n_mol - 1 - u nearly none).
+        const int iA = u, iB = n_mol - 1 - u;
+        const bool hasB = iB > iA; // the middle molecule of an odd count stands alone
+        double wA = 0.0, wB = 0.0;
+        if (lane < MMC_REC) {
+            wA = myrec[(int64_t)iA * MMC_RSTRIDE + lane];
+            if (hasB)
+                wB = myrec[(int64_t)iB * MMC_RSTRIDE + lane];
+        }
+
+        auto process = [&](int cnt) {
+            wave_sync();
+            for (int n0 = 0; n0 < cnt; n0 += 64) {
+                const int n = n0 + lane;
+                const bool act = n < cnt;
+                const int ent = act ? list[n] : 0;
+                const int j = ent & ((1 << 27) - 1);
+                const bool isB = (ent >> 27) != 0;
+                double t[MMC_REC];
+                const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_RSTRIDE);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double2 v = src[q];
+                    t[2 * q] = v.x;
+                    t[2 * q + 1] = v.y;
+                }
+                // this lane's own molecule: a per-lane choice between two scalars
+                auto mine = [&](int word) {
+                    const double va = lane_f64(wA, word), vb = lane_f64(wB, word);
+                    return isB ? vb : va;
+                };
+                const double ccx = mine(9), ccy = mine(10), ccz = mine(11);
+                // the gate, exactly (energy.jl:248-254, ewalds.jl:334-340)
+                const double x0 = vector1D_abs(ccx, t[9], bc), y0 = vector1D_abs(ccy, t[10], bc),
+                             z0 = vector1D_abs(ccz, t[11], bc);
+                const double c0 = x0 * x0 + y0 * y0 + z0 * z0;
+                const bool g0 = act && (c0 < pp.qq_gate_sq);
+                const bool l0 = same_gate ? g0 : (act && (c0 < pp.lj_gate_sq));
+                auto pair_ab = [&](int ab, double ax, double ay, double az, double bx, double by,
+                                   double bz) {
+                    const double qq = fc.qq9[ab];
+                    const bool qneg = qq < 0;
+                    const double px = vector1D_abs(ax, bx, bc), py = vector1D_abs(ay, by, bc),
+                                 pz = vector1D_abs(az, bz, bc);
+                    const double u0 = px * px + py * py + pz * pz;
+                    const bool ov0 = g0 && qneg && (u0 < pp.ovr);          // ewalds.jl:359
+                    const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq);  // ewalds.jl:362
+                    double e0 = qq_table_eval_clamped(sm.qtab, u0);
+                    if (__any(in0 && (u0 < pp.ovr))) {
+                        if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
+                    }
+                    a_q = fma(e0, in0 ? qq : 0.0, a_q);
+                    ovm |= __ballot(ov0);
+                    const double eps = fc.eps9[ab], sg = fc.sig9[ab];
+                    if (eps > 0.001) { // uniform (energy.jl:270)
+                        if (l0 && u0 < pp.lj_slack_sq) {
+                            const double s2 = sg * sg / u0;
+                            const double s6 = s2 * s2 * s2;
+                            const double s12 = s6 * s6;
+                            const double virab = eps * (2.0 * s12 - s6);
+                            const double f0 = vector1D(ax, bx, bc) * virab * s2,
+                                         f1 = vector1D(ay, by, bc) * virab * s2,
+                                         f2 = vector1D(az, bz, bc) * virab * s2;
+                            a_lj += eps * (s12 - s6);
+                            a_v += vector1D(ccx, t[9], bc) * f0 + vector1D(ccy, t[10], bc) * f1
+                                   + vector1D(ccz, t[11], bc) * f2;
+                        }
+                    }
+                };
+#pragma unroll 1
+                for (int a = 0; a < 3; a++) {
+                    const double ax = mine(3 * a), ay = mine(3 * a + 1), az = mine(3 * a + 2);
+                    pair_ab(3 * a, ax, ay, az, t[0], t[1], t[2]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair_ab(3 * a + 1, ax, ay, az, t[3], t[4], t[5]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pair_ab(3 * a + 2, ax, ay, az, t[6], t[7], t[8]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            wave_sync();
+        };
+
+        int cnt = 0;
+        for (int half = 0; half < (hasB ? 2 : 1); half++) {
+            const int i0 = half == 0 ? iA : iB;
+            const double w = half == 0 ? wA : wB;
+            float ccf[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                ccf[d] = (float)lane_f64(w, 9 + d);
+            // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1
+            int base = (i0 + 1) & ~63;
+            while (base < n_mol) {
+                float fx[WV_PF], fy[WV_PF], fz[WV_PF];
+#pragma unroll
+                for (int b = 0; b < WV_PF; b++) {
+                    const int j = base + 64 * b + lane;
+                    fx[b] = fy[b] = fz[b] = 0.f;
+                    if (j < n_mol) { fx[b] = cfx[j]; fy[b] = cfy[j]; fz[b] = cfz[j]; }
+                }
+                while (base < n_mol && cnt <= WV_LIST - 64) {
+#pragma unroll
+                    for (int b = 0; b < WV_PF; b++) {
+                        if (base < n_mol && cnt <= WV_LIST - 64) { // uniform
+                            const int j = base + lane;
+                            const float x = fx[b], y = fy[b], z = fz[b];
+                            {
+                                const int jn = base + 64 * WV_PF + lane;
+                                fx[b] = fy[b] = fz[b] = 0.f;
+                                if (jn < n_mol) { fx[b] = cfx[jn]; fy[b] = cfy[jn]; fz[b] = cfz[jn]; }
+                            }
+                            float dx = fabsf(x - ccf[0]), dy = fabsf(y - ccf[1]), dz = fabsf(z - ccf[2]);
+                            dx = fminf(dx, boxf - dx);
+                            dy = fminf(dy, boxf - dy);
+                            dz = fminf(dz, boxf - dz);
+                            const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                            const bool keep = (r2 < gatef) && (j < n_mol) && (j > i0);
+                            const unsigned long long m = __ballot(keep);
+                            if (keep)
+                                list[cnt + lanes_below(m)] = j | (half << 27);
+                            cnt += __popcll(m);
+                            base += 64;
+                        }
+                    }
+                }
+                if (cnt > WV_LIST - 64) { // the list is full: empty it and go on scanning
+                    process(cnt);
+                    cnt = 0;
+                }
+            }
+        }
+        if (cnt)
+            process(cnt);
+        const double s0 = wave_sum(a_lj), s1 = wave_sum(a_v), s2 = wave_sum(a_q);
+        if (lane == 0) {
+            TotalPart o;
+            o.lj_pot = s0; o.lj_vir = s1; o.qq = s2;
+            o.n_ovl = ovm != 0ULL ? 1 : 0;
+            o._pad = 0;
+            out[unit] = o;
+        }
+    }
+}
+
+// Per replica: the unit partials added in index order by one workgroup (fixed order: bitwise
+// reproducible), in the reference's normalisation (sum_i 4 pot_i etc., pairs counted once -> x2,
+// which the host halves again; energy.jl:289, :978-980).
+__global__ __launch_bounds__(MMC_BLOCK) void k_total_reduce(const TotalPart *parts, int n_parts,
+                                                             TotalsRaw *out)
+{
+    __shared__ double red[4 * MMC_WAVES];
+    const int r = blockIdx.x;
+    const TotalPart *p = parts + (int64_t)r * n_parts;
+    double v[4] = { 0, 0, 0, 0 }, tot[4];
+    for (int k = threadIdx.x; k < n_parts; k += MMC_BLOCK) {
+        v[0] += p[k].lj_pot; v[1] += p[k].lj_vir; v[2] += p[k].qq; v[3] += (double)p[k].n_ovl;
+    }
+    block_sum<4>(v, red, tot);
+    if (threadIdx.x == 0) {
+        TotalsRaw t;
+        t.lj_e = 2.0 * (tot[0] * 4);
+        t.lj_v = 2.0 * (tot[1] * 24 / 3.0);
+        t.qq = 2.0 * tot[2];
+        t.n_ovl = tot[3] > 0 ? 1 : 0;
+        t._pad = 0;
+        out[r] = t;
+    }
+}
