@@ -54,6 +54,9 @@ struct DeviceSystem {
     int n_tile_pairs = 0;
     TotalPart *d_tparts = nullptr; // [R][n_tile_pairs], lazily
     double *d_phase = nullptr;     // [R][n_atoms][6], lazily (k_atom_phases)
+    double *d_spart = nullptr;     // [R][16][2 * MMC_NK_STRIDE] chunk partials of S(k), lazily
+    bool sums_valid = false;       // c_sq / c_sq2 = sum q, sum q^2 of the uploaded charges
+    double c_sq = 0.0, c_sq2 = 0.0;
     bool fast_table_ok(double qq_rcut) const; // the erfc table covers this cutoff
     int64_t nk = 0, k_sq_max = 0, nkvecs = 0;
     BatchView bv{};
@@ -85,6 +88,9 @@ struct DeviceSystem {
     int32_t mol_energy(int i_base, int n_sel, bool lj, bool qq, int style, const PairParams &pp,
                        MolE *out, int out_stride);
     int32_t recip_long_all(double *energies_host /* [R] */);
+    int32_t recip_long_enqueue(double *energies_host /* [R] */);
+    int32_t pair_totals_enqueue(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht, bool *fast);
+    int32_t pair_totals_finish(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht, bool fast);
     int32_t totals_ewald(double lj_rcut, double qq_rcut, mmc_totals *tot /* [R] */);
     // sum_i 4 pot_i, sum_i 8 vir_i, sum_i EwaldReal_i and the overlap count, per replica
     int32_t pair_totals(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht);

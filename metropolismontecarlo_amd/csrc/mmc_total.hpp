@@ -253,7 +253,12 @@ __global__ void k_atom_phases(BatchView bv, double *ph)
 }
 
 // k_recip_long with the phases read instead of recomputed per (kx, ky) column.
-__global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const double *ph)
+// grid (66 columns, R, n_chunks): with n_chunks > 1 (few replicas: the 66 workgroups of one
+// system would leave most of the chip idle and walk all atoms serially) chunk c sums atoms
+// [c * chunk_len, (c + 1) * chunk_len) into spart[r][c][k] and k_recip_finish adds the chunks in
+// index order; with one chunk the sums go straight to S.
+__global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const double *ph,
+                                                             double *spart, int chunk_len)
 {
     __shared__ double red[2 * MMC_NKTAB * MMC_WAVES];
     const int r = blockIdx.y;
@@ -275,7 +280,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
 #pragma unroll
     for (int k = 0; k < 2 * MMC_NKTAB; k++)
         acc[k] = 0.0;
-    for (int l = threadIdx.x; l < bv.n_atoms; l += MMC_BLOCK) {
+    const int l_begin = blockIdx.z * chunk_len, l_end = min(l_begin + chunk_len, (int)bv.n_atoms);
+    for (int l = l_begin + threadIdx.x; l < l_end; l += MMC_BLOCK) {
         const double q = bv.charge[l];
         const double2 px = *reinterpret_cast<const double2 *>(myph + 6 * l),
                       py = *reinterpret_cast<const double2 *>(myph + 6 * l + 2),
@@ -318,6 +324,8 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
     block_sum<2 * MMC_NKTAB>(acc, red, tot);
     if (threadIdx.x == 0) {
         double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
+        if (gridDim.z > 1) // a partial sum: both targets are this chunk's row of the scratch
+            s0 = s1 = spart + ((int64_t)r * gridDim.z + blockIdx.z) * bv.nk_stride * 2;
 #pragma unroll
         for (int k = 0; k < MMC_NKTAB; k++) {
             const int idx = col[k];
@@ -327,4 +335,17 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
             }
         }
     }
+}
+
+// S(k) = sum of the chunk partials in chunk order (both arrays get `term`, ewalds.jl:600-601).
+__global__ void k_recip_finish(BatchView bv, const double *spart, int n_chunks)
+{
+    const int r = blockIdx.y, k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= 2 * bv.nkvecs)
+        return;
+    double s = 0.0;
+    for (int c = 0; c < n_chunks; c++)
+        s += spart[((int64_t)r * n_chunks + c) * bv.nk_stride * 2 + k];
+    s_buf(bv, r, 0)[k] = s;
+    s_buf(bv, r, 1)[k] = s;
 }

@@ -525,7 +525,7 @@ struct TotalWaveShared {
 #define WV_TOTAL_WAVES_PER_SIMD 5 // 87 VGPRs: the single-state pair loop needs fewer than the move kernel
 __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_total_wave(
     BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
-    PairParams pp, TotalPart *out, int units_per_rep, int n_units)
+    PairParams pp, TotalPart *out, int units_per_rep, int n_units, int paired)
 {
     __shared__ __align__(16) TotalWaveShared sm;
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -556,8 +556,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         // of both go into ONE list, tagged with the molecule they belong to, so that the pair
         // loop runs on full batches whatever the split between the two (molecule u has nearly all
         // of its neighbours above it, molecule n_mol - 1 - u nearly none).
+        // (paired == 0: one molecule per unit -- twice the waves with uneven work, for the latency
+        // of a single system's evaluation)
         const int iA = u, iB = n_mol - 1 - u;
-        const bool hasB = iB > iA; // the middle molecule of an odd count stands alone
+        const bool hasB = paired && iB > iA; // the middle molecule of an odd count stands alone
         double wA = 0.0, wB = 0.0;
         if (lane < MMC_REC) {
             wA = myrec[(int64_t)iA * MMC_RSTRIDE + lane];
