@@ -7,22 +7,34 @@
 Workload (BASELINE.json configs[1]/[2]): SPC/E water, 750 molecules (NIST sample configuration 4 ==
 Ewald/coord750.txt, committed as tests/golden/spce_nist.npz), NVT at 298.15 K, full Ewald
 (kappa = 5.6/L, 337 k-vectors), fp64, r_cut = 10 A.  R independent replicas per GPU (one Markov
-chain each, RNG stream seed 11234 + global replica index); replicas shard across ranks with no
-data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of every
-replica of the rank: one fused launch of k_move_eval_fast (2x LJ_poly_dU + 2x EwaldShort +
+chain each; chain r of rank k draws from the stream (seed, k*R + r)); replicas shard across ranks
+with no data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of
+every replica of the rank: one fused launch of the move kernel (2x LJ_poly_dU + 2x EwaldShort +
 RecipMove + commit of the previous accepted move) per replica group, followed by the sequential
 Metropolis accept/reject on the host (native C++ driver, mmc_batch_run).  Inputs are resident in
 HBM before the timed region; the trial moves are drawn on the device (k_propose, Philox4x32-10),
 so per step one flag byte per replica travels to the device and 64 B of results come back
-(--device-moves 0: the host draws the moves and sends 200 B per replica and step).
+(--device-moves 0: the host draws the moves and sends 232 B per replica and step).
+
+The default R = 65536 fills the device (the headline line).  BASELINE's two named replica counts
+are first-class too: `--replicas 1` (configs[1]) and `--replicas 32` (configs[2]'s share of one
+GPU) print the same contract line with their own roofline object; the default run also carries
+both as `named_configs`.
 
 One JSON line on stdout (rank 0).  Extra objects:
-  roofline      dominant kernel k_move_eval_fast: algorithmic bytes per launch (SURVEY.md section
-                8d: 78.7 KB per trial move at 750 molecules x replicas per launch) / average launch
-                duration measured with HIP events on the kernel's own stream inside the timed
-                region (every --event-every'th launch), against the 8 TB/s HBM peak.
-  cpu_baseline  the CPU oracle (a single-threaded C port of the reference's Julia code path; the
-                Julia reference itself cannot run here) timed on this host on the same workload.
+  roofline       dominant kernel (k_move_eval_wave for launches of >= 16 moves per CU, else
+                 k_move_eval_fast): algorithmic bytes per launch (78.7 KB per
+                 trial move at 750 molecules x moves per launch) / average launch duration measured
+                 with HIP events on the kernel's own stream inside the timed region (every
+                 --event-every'th launch), against the 8 TB/s HBM peak.  `traffic` is NOT measured
+                 in this run (PMC counters cannot be read from inside the process): it is the
+                 rocprofv3 figure of the same command committed under profiles/, quoted only when
+                 the launch shape matches, and `traffic_source` says so.
+  full_energy_eval  M2: ns per potential(..., "ewald"), batched over the replicas and as the
+                 latency of ONE system (750 and 10 000 molecules), each with its fraction of the
+                 fp64 vector peak on the survey's flop count.
+  cpu_baseline   the CPU oracle (a single-threaded C port of the reference's Julia code path; the
+                 Julia reference itself cannot run here) timed on this host on the same workload.
 """
 import argparse
 import json
@@ -42,7 +54,9 @@ DPHI_MAX = 0.05           # Ewald/main.jl:73
 RCUT = 10.0               # Ewald/main.jl:67
 SEED = 11234              # Monatomic/mainMonatomic.jl:15
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak (datasheet)
 N_K = 337
+N_CUS = 256
 
 
 def algorithmic_bytes_per_move(n_mol, box, r_cut=RCUT, n_k=N_K):
@@ -57,20 +71,29 @@ def algorithmic_bytes_full_eval(n_mol, n_k=N_K):
     return 36 * 3 * n_mol + 24 * n_mol + 36 * n_k
 
 
-def pmc_traffic(args, moves_per_launch):
+def algorithmic_flops_full_eval(n_mol, box, r_cut=RCUT, n_k=N_K):
+    """half-pair COM tests (12 flop), 9 x 48-flop atom-pair terms + one
+    12-flop LJ term per molecule pair inside the gate, 16-flop phase terms, 120 flop of phase
+    set-up per atom."""
+    mbar = 4.0 / 3.0 * np.pi * r_cut ** 3 * n_mol / box ** 3
+    return (12 * n_mol * (n_mol - 1) / 2 + (9 * 48 + 12) * n_mol * mbar / 2
+            + 16 * n_k * 3 * n_mol + 120 * 3 * n_mol)
+
+
+def pmc_traffic(kernel, moves_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 on gfx950; profiles/*_traffic.json).
-    PMC counters cannot be collected from inside this process, so the number is reported only when
-    this run has the launch shape the counters were collected for; otherwise null."""
+    (FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE x2 on gfx950; profiles/*_traffic.json),
+    only when this run has the kernel and launch shape the counters were collected for."""
     try:
         path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
                       if p.endswith("_traffic.json"))[-1]
         t = json.load(open(os.path.join(ROOT, "profiles", path)))
     except (IndexError, OSError, ValueError):
-        return None
-    if args.kernel != 1 or int(moves_per_launch) != int(t["moves_per_launch"]):
-        return None
-    return t["bytes_per_launch"]
+        return None, None
+    if t.get("kernel") != kernel or int(moves_per_launch) != int(t["moves_per_launch"]):
+        return None, None
+    return t["bytes_per_launch"], (f"profiles/{path}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                   "command (committed); not measured in this run")
 
 
 def cpu_baseline(a, budget_s, n_threads=1):
@@ -90,28 +113,165 @@ def cpu_baseline(a, budget_s, n_threads=1):
     return n / dt, n, dt, t_full
 
 
+def default_parts(R, n_mol):
+    """The library's default number of units per move (batch_default_parts, csrc/mmc_batch.inc)."""
+    if R >= 8192:
+        return 1
+    return int(max(1, min((2048 + R - 1) // R, 1 + (n_mol + 187) // 188, 16)))
+
+
+def kernel_name(kernel_opt, moves_per_launch, parts):
+    if kernel_opt == 0:
+        return "k_move_eval"
+    if kernel_opt in (1, 2):
+        return {1: "k_move_eval_fast", 2: "k_move_eval_wave"}[kernel_opt]
+    return "k_move_eval_wave" if moves_per_launch * parts >= 16 * N_CUS else "k_move_eval_fast"
+
+
+def shape_for(R, args):
+    """Launch shape for R replicas per GPU: groups, host threads, steps, warm-up.  Small batches
+    are latency-bound: one group for a single chain, proposals read in place (no H2D copy in the
+    step), and enough steps for a stable clock."""
+    small = R < 4096
+    groups = args.groups if args.groups > 0 else (1 if R == 1 else 2)
+    threads = args.threads
+    if small:
+        threads = min(threads, groups)
+    steps = args.steps if args.steps is not None else (3000 if small else 600)
+    warmup = args.warmup if args.warmup is not None else (300 if small else 60)
+    zero_copy = args.zero_copy_moves if args.zero_copy_moves >= 0 else (1 if small else 0)
+    return dict(groups=groups, threads=max(threads, 1), steps=steps, warmup=warmup,
+                zero_copy=zero_copy)
+
+
+def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None):
+    """One timed run of the native driver on a fresh batch of R replicas.  Returns the figures of
+    this rank; the caller reduces over ranks."""
+    from metropolismontecarlo_amd import sharding, structs
+    from metropolismontecarlo_amd.device import Batch
+    box = a["box"]
+    b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
+              5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
+    b.set_option("kernel", args.kernel)
+    if args.wave_wgs:
+        b.set_option("wave_wgs", args.wave_wgs)
+    b.set_option("zero_copy_moves", shape["zero_copy"])
+    b.set_option("device_moves", args.device_moves)
+    parts = args.parts if n_parts is None else n_parts
+    # initial total energy of every replica (also initialises S(k)): the M2 metric, batched
+    b.potential_ewald(as_array=True)
+    barrier()
+    t0 = time.perf_counter()
+    tot = b.potential_ewald(as_array=True)      # mmc_totals[R] written straight into numpy
+    t_full = time.perf_counter() - t0
+    energies = tot["energy"].copy()
+    ev = 0 if args.no_events else max(1, args.event_every)
+    kw = dict(n_groups=shape["groups"], n_parts=parts, time_kernels=ev, n_threads=shape["threads"],
+              n_streams=args.streams, replica0=g0)
+    energies, _ = b.run(shape["warmup"], TEMPERATURE, DR_MAX, DPHI_MAX, sharding.run_seed(phase=0),
+                        energies, **kw)
+    barrier()
+    t0 = time.perf_counter()
+    energies, st = b.run(shape["steps"], TEMPERATURE, DR_MAX, DPHI_MAX, sharding.run_seed(phase=1),
+                         energies, **kw)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # consistency: running totals vs a full recompute (Poly/main.jl:232-235), outside the timing
+    tot2 = b.potential_ewald(as_array=True)
+    drift = float(np.max(np.abs(energies - tot2["energy"]) / np.abs(energies)))
+    b.close()
+    return dict(st=st, elapsed=elapsed, t_full=t_full, drift=drift, energy_sum=float(energies.sum()),
+                launches_per_step=st["launches"] / max(shape["steps"], 1))
+
+
+def roofline_object(res, R, args, shape, n_mol, box, parts_used):
+    st = res["st"]
+    if args.no_events or not st["timed_launches"]:
+        return None
+    bytes_move = algorithmic_bytes_per_move(n_mol, box)
+    moves_per_launch = st["moves"] / max(st["launches"], 1)
+    t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
+    achieved = bytes_move * moves_per_launch / t_launch / 1e9
+    name = kernel_name(args.kernel, moves_per_launch, parts_used)
+    traffic, source = pmc_traffic(name, moves_per_launch)
+    return {
+        "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+        "avg_launch_us": 1e6 * t_launch, "launches": int(st["launches"]),
+        "launches_timed_with_events": int(st["timed_launches"]),
+        "algorithmic_bytes_per_move": bytes_move, "moves_per_launch": moves_per_launch,
+        "launches_per_move": st["launches"] / max(st["moves"], 1),
+        "frac_of_measured_copy_peak_6290": achieved / 6290.0,
+    }
+
+
+def single_system_latency(a, local_rank):
+    """Latency of ONE potential(..., "ewald") call (what a Julia caller of `potential` sees), at
+    750 molecules (NIST configuration 4) and at 10 000 (the lattice of BASELINE configs[3])."""
+    from metropolismontecarlo_amd import io as mio
+    from metropolismontecarlo_amd import structs
+    from metropolismontecarlo_amd.device import Context
+    out = {}
+    for nm in (750, 10000):
+        if nm == 750:
+            s, first, last = a, a["first_atom"], a["last_atom"]
+        else:
+            box4, com4, coords4 = mio.cubic_lattice_water(nm, 0.033101144, "spce", seed=SEED)
+            first = 3 * np.arange(nm, dtype=np.int64) + 1
+            last = first + 2
+            s = dict(com=com4, coords=coords4, atype=np.tile([1, 2, 2], nm),
+                     charge=np.tile([mio.SPCE_Q_O, mio.SPCE_Q_H, mio.SPCE_Q_H], nm), eps=a["eps"],
+                     sig=a["sig"], box=box4)
+        ctx = Context(local_rank)
+        ctx.upload_system(s["com"], first, last, s["coords"], s["atype"], s["charge"], s["eps"],
+                          s["sig"], s["box"])
+        ctx.prepare_ewald(5.6 / s["box"], 5, 27, s["box"], structs.factor)
+        ctx.potential_ewald(RCUT, RCUT)
+        n = 50 if nm == 750 else 20
+        t0 = time.perf_counter()
+        for _ in range(n):
+            e = ctx.potential_ewald(RCUT, RCUT)["energy"]
+        dt = (time.perf_counter() - t0) / n
+        fl = algorithmic_flops_full_eval(nm, s["box"])
+        out[f"{nm}_molecules"] = {"us": 1e6 * dt, "energy_K": e, "algorithmic_flops": fl,
+                                  "frac_fp64_vector_peak": fl / dt / 1e12 / FP64_PEAK_TFLOPS}
+        if nm == 10000:   # configs[3]: NPT volume move = K6 + table + K2 + K3, volume +-0.5 %
+            n_vol, t0 = 20, time.perf_counter()
+            for i in range(n_vol):
+                L4 = (s["box"] ** 3 * (1.005 if i % 2 == 0 else 1.0)) ** (1.0 / 3.0)
+                ctx.volume_change(L4, 5.6 / L4)
+                e4 = ctx.potential_ewald(RCUT, RCUT)["energy"]
+            out["npt_volume_move_10000"] = {"ms": 1e3 * (time.perf_counter() - t0) / n_vol,
+                                            "energy_K": e4}
+        ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=600)
-    ap.add_argument("--warmup", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=None, help="default 600 (3000 below 4096 replicas)")
+    ap.add_argument("--warmup", type=int, default=None, help="default 60 (300 below 4096 replicas)")
     ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
-    ap.add_argument("--groups", type=int, default=2, help="replica groups pipelined per GPU")
-    ap.add_argument("--parts", type=int, default=0, help="workgroups per replica-move (0=auto)")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="replica groups pipelined per GPU (0 = 2, or 1 for a single chain)")
+    ap.add_argument("--parts", type=int, default=0, help="units per replica-move (0=auto)")
     ap.add_argument("--threads", type=int, default=0,
                     help="host threads per GPU for the accept/reject (0 = min(4, cores / ranks))")
-    ap.add_argument("--kernel", type=int, default=2,
-                    help="2 = wave per move (default), 1 = workgroup per move, 0 = generic")
+    ap.add_argument("--kernel", type=int, default=3,
+                    help="3 = by launch size (default), 2 = wave per move, 1 = workgroup per move, "
+                         "0 = generic")
     ap.add_argument("--wave-wgs", type=int, default=0,
                     help="workgroups of a kernel-2 launch (0 = library default)")
-    ap.add_argument("--zero-copy-moves", type=int, default=0)
+    ap.add_argument("--zero-copy-moves", type=int, default=-1,
+                    help="1 = the kernel reads host-written records in place (-1 = only below 4096 replicas)")
     ap.add_argument("--device-moves", type=int, default=1,
                     help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the 1-replica and 32-replica side measurements")
+                    help="skip the named-config and single-system side measurements")
     ap.add_argument("--no-events", action="store_true",
                     help="do not bracket launches with HIP events in the timed region")
     ap.add_argument("--event-every", type=int, default=8,
@@ -149,76 +309,44 @@ def main():
             dist.init_process_group(backend)
 
     import common
-    from metropolismontecarlo_amd import sharding, structs
-    from metropolismontecarlo_amd.device import Batch
+    from metropolismontecarlo_amd import sharding
 
     a = common.nist_arrays(4, "unwrapped")
     n_mol, box = a["com"].shape[0], a["box"]
     R = args.replicas
-    b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
-              5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
-    b.set_option("kernel", args.kernel)
-    if args.wave_wgs:
-        b.set_option("wave_wgs", args.wave_wgs)
-    b.set_option("zero_copy_moves", args.zero_copy_moves)
-    b.set_option("device_moves", args.device_moves)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # initial total energy of every replica (also initialises S(k)): the M2 metric
-    b.potential_ewald(as_array=True)
-    barrier()
-    t0 = time.perf_counter()
-    tot = b.potential_ewald(as_array=True)      # mmc_totals[R] written straight into numpy
-    t_full = time.perf_counter() - t0
-    energies = tot["energy"].copy()
-    e_start = energies.copy()
-
-    # chain r of this rank has global index rank*R + r and draws from stream seed + r (the driver
-    # adds r): trajectories depend on the global index only, not on the number of GPUs
+    # chain r of this rank has global index rank*R + r: trajectories depend on the global index
+    # only, not on the number of GPUs
     g0 = sharding.shard(R, rank)[0]
-    ev = 0 if args.no_events else max(1, args.event_every)
-    energies, _ = b.run(args.warmup, TEMPERATURE, DR_MAX, DPHI_MAX,
-                        sharding.run_seed(phase=0), energies,
-                        n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                        n_threads=args.threads, n_streams=args.streams, replica0=g0)
-    barrier()
-    t0 = time.perf_counter()
-    energies, st = b.run(args.steps, TEMPERATURE, DR_MAX, DPHI_MAX,
-                         sharding.run_seed(phase=1), energies,
-                         n_groups=args.groups, n_parts=args.parts, time_kernels=ev,
-                         n_threads=args.threads, n_streams=args.streams, replica0=g0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-
-    # consistency: running totals vs a full recompute (Poly/main.jl:232-235), outside the timing
-    tot2 = b.potential_ewald(as_array=True)
-    drift = float(np.max(np.abs(energies - tot2["energy"]) / np.abs(energies)))
+    shape = shape_for(R, args)
+    res = measure_moves(R, a, args, local_rank, g0, barrier, shape)
+    st = res["st"]
 
     # C1: the only collective -- max of the time, sums of the observables (RCCL all-reduce)
     local = dict(moves=st["moves"], accepted=st["trans_accept"] + st["rot_accept"],
-                 overlaps=st["overlaps"], energy_sum=float(energies.sum()),
+                 overlaps=st["overlaps"], energy_sum=res["energy_sum"],
                  kernel_ms=st["kernel_ms"], launches=st["launches"])
     d = dist if world > 1 else None
-    red, elapsed_max = sharding.reduce_observables(local, elapsed, d, device=red_device)
-    _, t_full_max = sharding.reduce_observables(local, t_full, d, device=red_device)
+    red, elapsed_max = sharding.reduce_observables(local, res["elapsed"], d, device=red_device)
+    _, t_full_max = sharding.reduce_observables(local, res["t_full"], d, device=red_device)
+    _, drift_max = sharding.reduce_observables(local, res["drift"], d, device=red_device)
     total_moves = red["moves"]
 
     if rank == 0:
-        bytes_move = algorithmic_bytes_per_move(n_mol, box)
-        launches = st["launches"]
-        replicas_per_launch = st["moves"] / max(launches, 1)
+        parts_used = args.parts if args.parts > 0 else default_parts(R, n_mol)
         out = {
             "metric": "MC trial moves/sec (whole node), SPC/E NVT full Ewald fp64",
             "value": total_moves / elapsed_max,
             "unit": "moves/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / max(args.steps, 1),
+            "steps": shape["steps"],
+            "warmup": shape["warmup"],
+            "ms_per_step": 1e3 * elapsed_max / max(shape["steps"], 1),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -228,42 +356,28 @@ def main():
             "config": {"workload": "SPC/E 750 molecules NVT 298.15 K, full Ewald (337 k), "
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
-                       "groups_per_gpu": args.groups, "host_threads_per_gpu": args.threads,
+                       "groups_per_gpu": shape["groups"], "host_threads_per_gpu": shape["threads"],
                        "move_generation": "device" if args.device_moves else "host",
                        "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),
             "overlaps": int(red["overlaps"]),
+            "torn_result_records": int(st["torn_records"]),
             "energy_mean_per_replica": red["energy_sum"] / (R * world),
-            "energy_drift_rel": drift,
+            "energy_drift_rel": drift_max,
             "ns_per_full_energy_eval": 1e9 * t_full_max / R,
             "full_energy_evals_per_s": R * world / t_full_max,
         }
         # M2: a full evaluation is fp64-VALU work, 3.5e7 flop by the survey's
-        # counting (half-pair COM tests, 9 x 48-flop atom-pair terms, 16-flop phase terms) against
-        # 111 KB of compulsory bytes -> quote the fraction of the 78.6 TFLOP/s fp64 vector peak
-        flops_full = (12 * n_mol * (n_mol - 1) / 2 + (9 * 48 + 12) * n_mol
-                      * (4.0 / 3.0 * np.pi * RCUT ** 3 * n_mol / box ** 3) / 2
-                      + 16 * N_K * 3 * n_mol + 120 * 3 * n_mol)
+        # counting against 111 KB of compulsory bytes -> fraction of the fp64 vector peak
+        flops_full = algorithmic_flops_full_eval(n_mol, box)
         out["full_energy_eval"] = {
             "ns": 1e9 * t_full_max / R, "batched_over_replicas": R,
             "algorithmic_flops": flops_full, "algorithmic_bytes": algorithmic_bytes_full_eval(n_mol),
             "achieved_tflops_per_gpu": flops_full * R / t_full_max / 1e12,
-            "frac_fp64_vector_peak_78.6": flops_full * R / t_full_max / 78.6e12}
-        if ev and st["timed_launches"]:
-            # rank 0's average launch duration over the launches that carried events
-            t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
-            achieved = bytes_move * replicas_per_launch / t_launch / 1e9
-            out["roofline"] = {
-                "kernel": {2: "k_move_eval_wave", 1: "k_move_eval_fast", 0: "k_move_eval"}[args.kernel],
-                "bound": "hbm", "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(args, replicas_per_launch),
-                "avg_launch_us": 1e6 * t_launch, "launches": int(launches),
-                "launches_timed_with_events": int(st["timed_launches"]),
-                "algorithmic_bytes_per_move": bytes_move,
-                "moves_per_launch": replicas_per_launch,
-                "frac_of_measured_copy_peak_6290": achieved / 6290.0,
-            }
+            "frac_fp64_vector_peak_78.6": flops_full * R / t_full_max / 1e12 / FP64_PEAK_TFLOPS}
+        rf = roofline_object(res, R, args, shape, n_mol, box, parts_used)
+        if rf:
+            out["roofline"] = rf
         # raw work counts: per trial move 2 states x (N_mol - 1) COM tests,
         # 2 x 9 x Mbar atom-pair terms (Mbar = 116.4 neighbours inside the COM gate), 337 x 6 phase
         # terms; launches of the move kernel per move; the driver never synchronises a stream
@@ -272,50 +386,33 @@ def main():
         out["work_counts"] = {
             "com_tests_per_s": v * 2 * (n_mol - 1), "atom_pair_terms_per_s": v * 2 * 9 * mbar,
             "lj_pair_terms_per_s": v * 2 * mbar, "phase_terms_per_s": v * N_K * 6,
-            "move_kernel_launches_per_move": launches / max(st["moves"], 1),
+            "move_kernel_launches_per_move": st["launches"] / max(st["moves"], 1),
             "stream_syncs_per_move": 0.0,
-            "pcie_bytes_per_move": {"h2d": 1 if args.device_moves else 200, "d2h": 64}}
+            "pcie_bytes_per_move": {"h2d": 1 if args.device_moves else 232, "d2h": 64 * parts_used}}
         if not args.no_secondary and world == 1:   # side measurements: single-GPU runs only
-            # the same path at BASELINE's two named replica counts, on this rank's GPU:
+            # BASELINE's two named replica counts on this GPU, each with its own roofline object:
             # configs[1] = one chain (latency-bound), configs[2] = 256 replicas over 8 GPUs = 32/GPU
-            out["other_configs"] = {}
-            for name, r2, g2, t2 in (("configs[1]: 1 replica on 1 GPU", 1, 1, 1),
-                                     ("configs[2] share: 32 replicas per GPU", 32, 2, 2)):
-                b2 = Batch(r2, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"],
-                           box, 5.6 / box, structs.factor, RCUT, RCUT, device=local_rank)
-                b2.set_option("zero_copy_moves", 1)   # latency-bound: no H2D copy in the step
-                e2 = np.array([t["energy"] for t in b2.potential_ewald()])
-                e2, _ = b2.run(200, TEMPERATURE, DR_MAX, DPHI_MAX, SEED, e2, n_groups=g2,
-                               n_threads=t2)
-                t0 = time.perf_counter()
-                e2, s2 = b2.run(2000, TEMPERATURE, DR_MAX, DPHI_MAX, SEED + 1, e2, n_groups=g2,
-                                n_threads=t2)
-                dt2 = time.perf_counter() - t0
-                b2.close()
-                out["other_configs"][name] = {"moves_per_s_per_gpu": s2["moves"] / dt2,
-                                              "us_per_step": 1e6 * dt2 / 2000}
-            # configs[3]: 10 000 SPC/E, NPT volume move = K6 (new kappa, k-vectors, erfc table) +
-            # K2 (all molecule pairs) + K3 (structure factor), volume perturbed by +-0.5 %
-            from metropolismontecarlo_amd import io as mio
-            from metropolismontecarlo_amd.device import Context
-            nm4 = 10000
-            box4, com4, coords4 = mio.cubic_lattice_water(nm4, 0.033101144, "spce", seed=SEED)
-            first4 = 3 * np.arange(nm4, dtype=np.int64) + 1
-            ctx = Context(local_rank)
-            ctx.upload_system(com4, first4, first4 + 2, coords4, np.tile([1, 2, 2], nm4),
-                              np.tile([mio.SPCE_Q_O, mio.SPCE_Q_H, mio.SPCE_Q_H], nm4), a["eps"],
-                              a["sig"], box4)
-            ctx.prepare_ewald(5.6 / box4, 5, 27, box4, structs.factor)
-            ctx.potential_ewald(RCUT, RCUT)
-            n_vol, t0 = 20, time.perf_counter()
-            for i in range(n_vol):
-                L4 = (box4 ** 3 * (1.005 if i % 2 == 0 else 1.0)) ** (1.0 / 3.0)
-                ctx.volume_change(L4, 5.6 / L4)
-                e4 = ctx.potential_ewald(RCUT, RCUT)["energy"]
-            dt4 = time.perf_counter() - t0
-            ctx.close()
-            out["other_configs"]["configs[3]: 10 000 SPC/E, NPT volume move (K6+K2+K3)"] = {
-                "ms_per_volume_move": 1e3 * dt4 / n_vol, "energy_K": e4}
+            out["named_configs"] = {}
+            for name, r2 in (("configs[1]: 1 replica on 1 GPU", 1),
+                             ("configs[2] share: 32 replicas per GPU", 32)):
+                if r2 == R:
+                    continue
+                sh2 = shape_for(r2, argparse.Namespace(**{**vars(args), "steps": None, "warmup": None,
+                                                          "groups": 0, "zero_copy_moves": -1}))
+                r_ = measure_moves(r2, a, args, local_rank, 0, barrier, sh2, n_parts=0)
+                s2 = r_["st"]
+                entry = {"moves_per_s_per_gpu": s2["moves"] / r_["elapsed"],
+                         "us_per_step": 1e6 * r_["elapsed"] / sh2["steps"],
+                         "us_per_move_per_chain": 1e6 * r_["elapsed"] / sh2["steps"],
+                         "steps": sh2["steps"], "groups": sh2["groups"],
+                         "energy_drift_rel": r_["drift"],
+                         "ns_per_full_energy_eval": 1e9 * r_["t_full"] / r2}
+                rf2 = roofline_object(r_, r2, args, sh2, n_mol, box, default_parts(r2, n_mol))
+                entry["units_per_move"] = default_parts(r2, n_mol)
+                if rf2:
+                    entry["roofline"] = rf2
+                out["named_configs"][name] = entry
+            out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {
@@ -332,7 +429,6 @@ def main():
                     "sample": f"{n_all} trial moves, one independent chain per thread, "
                               f"{dt_all:.1f} s"}
         print(json.dumps(out))
-    b.close()
     if world > 1:
         dist.destroy_process_group()
 
