@@ -20,9 +20,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import common  # noqa: E402  (fixture loader: tests/golden/spce_nist.npz)
-from metropolismontecarlo_amd import moves, observables, structs  # noqa: E402
-from metropolismontecarlo_amd.device import Batch  # noqa: E402
-from metropolismontecarlo_amd.structs import Properties  # noqa: E402
+from metropolismontecarlo_amd import observables, structs  # noqa: E402
+from metropolismontecarlo_amd.device import Batch, block_line  # noqa: E402
 
 
 def main():
@@ -35,7 +34,6 @@ def main():
 
     a = common.nist_arrays(4, "unwrapped")
     n_mol, box, r_cut = a["com"].shape[0], a["box"], 10.0
-    rho = n_mol / box ** 3
     b = Batch(args.replicas, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
               5.6 / box, structs.factor, r_cut, r_cut)
     b.set_option("device_moves", 1)
@@ -45,14 +43,7 @@ def main():
     for blk in range(1, args.blocks + 1):
         b.run_chains(chains, args.sweeps * n_mol, args.temperature, seed=11234 + 1000 * blk,
                      adjust=True, n_threads=2)
-        c = chains[0]                                           # the block line of chain 0
-        press = moves.Pressure(Properties(virial=c["virial"]), rho, args.temperature, box ** 3)
-        print("Block: %4d, Energy: %8.2f, Ratio trans: %4.2f, dr_max: %4.2f, Ratio rot: %4.2f, "
-              "dphi_max: %4.2f, instant energy: %8.2f, overlap count: %4d, pressure: %8.2f"
-              % (blk, c["avg_energy"] / c["steps_taken"] / n_mol,
-                 c["trans_naccept"] / max(c["trans_attempt"], 1), c["dr_max"],
-                 c["rot_naccept"] / max(c["rot_attempt"], 1), c["dphi_max"],
-                 c["energy"] / n_mol, c["overlaps"], press))
+        print(block_line(chains[0], blk, n_mol, box))            # main.jl:667-679, chain 0
     mean = chains["energy"].mean() / n_mol
     err = chains["energy"].std() / n_mol / np.sqrt(args.replicas)
     drift = max(abs(chains["energy"][r] - t["energy"]) / abs(t["energy"])

@@ -345,6 +345,18 @@ typedef struct {
 int32_t mmc_batch_run_chains(mmc_batch *b, const mmc_run_params *p, mmc_chain *chains,
                              int32_t adjust, mmc_run_stats *stats);
 
+/* The status line Loop() prints after every block (Ewald/main.jl:667-679), from one chain's record:
+ *   "Block: %4d, Energy: %8.2f, Ratio trans: %4.2f, dr_max: %4.2f, Ratio rot: %4.2f, dphi_max: %4.2f,
+ *    instant energy: %8.2f, overlap count: %4d, pressure: %8.2f"
+ * with Energy = averages.energy / totalStepsTaken / n_mol, the two acceptance ratios
+ * naccept / attempt, instant energy = total.energy / n_mol, and
+ * pressure = ideal_term + total.virial / box^3: the reference hard-codes ideal_term = 4.60453
+ * (main.jl:677); pass rho * T for auxillary.jl:121-123's Pressure(vir, rho, T, vol).  A ratio with
+ * no attempt prints NaN, as Julia's 0/0 does.  Writes at most `len` bytes including the
+ * terminator; returns MMC_ERR_ARG if the line does not fit. */
+int32_t mmc_chain_block_line(const mmc_chain *chain, int64_t block, int64_t n_mol, double box,
+                             double ideal_term, char *buf, int64_t len);
+
 #ifdef __cplusplus
 }
 #endif

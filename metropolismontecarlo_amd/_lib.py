@@ -139,6 +139,7 @@ SIGNATURES = {
     "mmc_study_f32_move": [_vp, _i64, _dp, _dp, C.c_double, C.c_double, C.c_int32, _dp, _i32p],
     "mmc_philox4x32": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "mmc_batch_run_chains": [_vp, C.POINTER(RunParams), _vp, C.c_int32, C.POINTER(RunStats)],
+    "mmc_chain_block_line": [_vp, _i64, _i64, _d, _d, C.c_char_p, _i64],
 }
 _RESTYPE = {"mmc_last_error": C.c_char_p, "mmc_version": C.c_char_p}
 

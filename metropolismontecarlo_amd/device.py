@@ -32,6 +32,22 @@ def _i(a):
     return a.ctypes.data_as(_i64p)
 
 
+REFERENCE_IDEAL_TERM = 4.60453   # the ideal-gas term Loop() hard-codes in its block line (main.jl:677)
+
+
+def block_line(chain, block, n_mol, box, ideal_term=REFERENCE_IDEAL_TERM):
+    """Loop()'s status line of one block (Ewald/main.jl:667-679) from one row of the chains array
+    (mmc_chain_block_line).  ideal_term: the reference's literal 4.60453, or rho * T for
+    auxillary.jl:121-123's Pressure(vir, rho, T, vol)."""
+    row = np.ascontiguousarray(chain).reshape(1)
+    if row.dtype != CHAIN_DTYPE:
+        raise ValueError("chain must be a row of the array returned by Batch.new_chains()")
+    buf = C.create_string_buffer(512)
+    check(_lib.lib().mmc_chain_block_line(row.ctypes.data_as(C.c_void_p), int(block), int(n_mol),
+                                          float(box), float(ideal_term), buf, 512))
+    return buf.value.decode("utf-8")
+
+
 def device_count():
     n = C.c_int32()
     check(_lib.lib().mmc_device_count(C.byref(n)))

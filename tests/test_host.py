@@ -125,3 +125,35 @@ def test_rdf_restatement_and_normalisation_on_an_ideal_gas():
     assert hist[3] == ((rr > 2 * 0.2) & (rr <= 3 * 0.2)).sum()      # bin = ceil(r / dr), dr = 0.2
     r_, g = observables.normalize_rdf(hist, n, side, 1)
     assert np.allclose(r_[:2], [0.1, 0.3]) and abs(g[8:].mean() - 1.0) < 0.02
+
+
+def test_block_line_is_the_references_format():
+    """mmc_chain_block_line against the reference's @sprintf (Ewald/main.jl:667-679) applied to
+    the same bookkeeping by hand: a host function, no GPU needed."""
+    import numpy as np
+    from metropolismontecarlo_amd._lib import CHAIN_DTYPE
+    from metropolismontecarlo_amd.device import REFERENCE_IDEAL_TERM, block_line
+    from metropolismontecarlo_amd import moves
+    from metropolismontecarlo_amd.structs import Properties
+    c = np.zeros(1, dtype=CHAIN_DTYPE)
+    n_mol, box, blk = 750, 30.0, 7
+    c["dr_max"], c["dphi_max"] = 0.3166, 0.0512
+    c["energy"], c["virial"] = -17271541.515, -2.5e6
+    c["avg_energy"], c["steps_taken"] = -17270000.0 * 15000, 15000
+    c["overlaps"] = 3
+    c["trans_naccept"], c["trans_attempt"] = 5800, 7512
+    c["rot_naccept"], c["rot_attempt"] = 5621, 7488
+    want = ("Block: %4d, Energy: %8.2f, Ratio trans: %4.2f, dr_max: %4.2f, Ratio rot: %4.2f, "
+            "dϕ_max: %4.2f, instant energy: %8.2f, overlap count: %4d, pressure: %8.2f"
+            % (blk, -17270000.0 / n_mol, 5800 / 7512, 0.3166, 5621 / 7488, 0.0512,
+               -17271541.515 / n_mol, 3, 4.60453 + -2.5e6 / box / box / box))
+    assert REFERENCE_IDEAL_TERM == 4.60453
+    assert block_line(c[0], blk, n_mol, box) == want
+    # with the ideal-gas term of auxillary.jl:121-123 instead of the literal
+    rho, T = n_mol / box ** 3, 298.15
+    line = block_line(c[0], blk, n_mol, box, ideal_term=rho * T)
+    p = moves.Pressure(Properties(virial=-2.5e6), rho, T, box ** 3)
+    assert line.endswith("pressure: %8.2f" % p)
+    # no attempt yet: Julia prints NaN for 0/0
+    c["rot_attempt"] = c["rot_naccept"] = 0
+    assert "Ratio rot:  nan" in block_line(c[0], blk, n_mol, box).replace("NaN", "nan").replace("-nan", " nan")
