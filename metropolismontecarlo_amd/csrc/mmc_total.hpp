@@ -257,8 +257,12 @@ __global__ void k_atom_phases(BatchView bv, double *ph)
 // system would leave most of the chip idle and walk all atoms serially) chunk c sums atoms
 // [c * chunk_len, (c + 1) * chunk_len) into spart[r][c][k] and k_recip_finish adds the chunks in
 // index order; with one chunk the sums go straight to S.
-__global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const double *ph,
-                                                             double *spart, int chunk_len)
+// BLOCK = 256 (few replicas: short critical path) or 64 (many replicas: one wave walks all atoms
+// of its column, so the 22-value reduction -- a third of the 256-thread form's instructions --
+// is paid once per column instead of four times, and needs no LDS pass).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_recip_long_ph(BatchView bv, const double *ph,
+                                                         double *spart, int chunk_len)
 {
     __shared__ double red[2 * MMC_NKTAB * MMC_WAVES];
     const int r = blockIdx.y;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
     for (int k = 0; k < 2 * MMC_NKTAB; k++)
         acc[k] = 0.0;
     const int l_begin = blockIdx.z * chunk_len, l_end = min(l_begin + chunk_len, (int)bv.n_atoms);
-    for (int l = l_begin + threadIdx.x; l < l_end; l += MMC_BLOCK) {
+    for (int l = l_begin + threadIdx.x; l < l_end; l += BLOCK) {
         const double q = bv.charge[l];
         const double2 px = *reinterpret_cast<const double2 *>(myph + 6 * l),
                       py = *reinterpret_cast<const double2 *>(myph + 6 * l + 2),
@@ -321,7 +325,13 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_long_ph(BatchView bv, const
         }
     }
     double tot[2 * MMC_NKTAB];
-    block_sum<2 * MMC_NKTAB>(acc, red, tot);
+    if (BLOCK == 64) {
+#pragma unroll
+        for (int k = 0; k < 2 * MMC_NKTAB; k++)
+            tot[k] = (k >= 2 * k_lo && k <= 2 * k_hi + 1) ? wave_sum(acc[k]) : 0.0;
+    } else {
+        block_sum<2 * MMC_NKTAB>(acc, red, tot);
+    }
     if (threadIdx.x == 0) {
         double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
         if (gridDim.z > 1) // a partial sum: both targets are this chunk's row of the scratch
