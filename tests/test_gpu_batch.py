@@ -718,3 +718,30 @@ def test_driver_rereads_torn_records(device_moves):
     assert np.array_equal(res[0][0], res[1][0])
     for key in ("trans_accept", "rot_accept", "overlaps", "moves"):
         assert res[0][1][key] == res[1][1][key]
+
+
+def test_total_energy_kernels_of_large_batches(orc):
+    """R = 256 takes the many-replica forms of the total-energy kernels (a wave per pair of
+    molecules for the pair part, a wave per (kx, ky) column for the structure factor): replicas
+    holding three different configurations against the oracle, terms and S(k)."""
+    a1 = common.nist_arrays(1, "unwrapped")
+    a2 = common.nist_arrays(1, "reference")
+    rng = np.random.default_rng(3)
+    shifted = dict(a1, com=a1["com"].copy(), coords=a1["coords"].copy())
+    d = (rng.random(3) - 0.5) * 0.4
+    shifted["com"][17] += d
+    shifted["coords"][51:54] += d
+    R = 256
+    with make_batch(a1, R) as b:
+        b.set_replica(100, a2["com"], a2["coords"])
+        b.set_replica(R - 1, shifted["com"], shifted["coords"])
+        t = b.potential_ewald(as_array=True)
+        for r, a in ((0, a1), (100, a2), (R - 1, shifted), (R - 2, a1)):
+            s = common.oracle_system(a)
+            ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+            to = orc.potential_ewald(s, ew, RCUT, RCUT)
+            for key in ("energy", "virial", "lj", "real", "recip", "self"):
+                assert rel(t[key][r], to[key]) < TOL, (r, key, t[key][r], to[key])
+            S = b.get_replica(r)[2]
+            assert np.abs(S - ew.sumQExpNew).max() < 1e-11 * np.abs(ew.sumQExpNew).max(), r
+        assert np.array_equal(t["energy"][1:100], np.full(99, t["energy"][0]))
