@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "round_profile")
 DST = os.path.join(ROOT, "profiles")
 TAG = sys.argv[1] if len(sys.argv) > 1 else "round1"
-KERNEL = "k_move_eval_fast"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "k_move_eval_wave"
 
 
 def newest(pattern):
@@ -50,10 +50,25 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
     for r in csv.DictReader(open(newest(f"{name}/*/*counter_collection.csv"))):
         if KERNEL in r["Kernel_Name"]:
             agg[int(r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    grid = max(agg, key=lambda g: g)
+    grid = max(agg, key=lambda g: sum(len(v) for v in agg[g].values()))   # the main launch shape
     for c, v in agg[grid].items():
         pmc[c] = {"per_dispatch": sum(v) / len(v), "dispatches": len(v), "grid_threads": grid}
-json.dump({"trace": trace, "pmc": pmc}, open(os.path.join(DST, f"{TAG}_default_pmc_summary.json"), "w"), indent=1)
+derived = {}
+w = pmc.get("SQ_WAVES", {}).get("per_dispatch")
+if w:
+    for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SMEM"):
+        if c in pmc:
+            derived[c + "_per_move"] = pmc[c]["per_dispatch"] / moves_per_launch
+wc = pmc.get("SQ_WAVE_CYCLES", {}).get("per_dispatch")
+if wc:
+    for c in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU"):
+        if c in pmc:
+            derived[c + "_share_of_wave_cycles"] = pmc[c]["per_dispatch"] / wc
+if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
+    h, m = pmc["TCC_HIT_sum"]["per_dispatch"], pmc["TCC_MISS_sum"]["per_dispatch"]
+    derived["l2_hit_rate"] = h / (h + m)
+json.dump({"trace": trace, "pmc": pmc, "derived": derived},
+          open(os.path.join(DST, f"{TAG}_default_pmc_summary.json"), "w"), indent=1)
 
 fetch = pmc["FETCH_SIZE"]["per_dispatch"]
 write = pmc["WRITE_SIZE"]["per_dispatch"]
