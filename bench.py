@@ -144,9 +144,10 @@ def shape_for(R, args):
                 zero_copy=zero_copy)
 
 
-def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None):
+def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, persistent=None):
     """One timed run of the native driver on a fresh batch of R replicas.  Returns the figures of
-    this rank; the caller reduces over ranks."""
+    this rank; the caller reduces over ranks.  `persistent`: the move server for small batches
+    (None = the --persistent flag; the library's default takes it up to 64 replicas)."""
     from metropolismontecarlo_amd import sharding, structs
     from metropolismontecarlo_amd.device import Batch
     box = a["box"]
@@ -157,6 +158,8 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None):
         b.set_option("wave_wgs", args.wave_wgs)
     b.set_option("zero_copy_moves", shape["zero_copy"])
     b.set_option("device_moves", args.device_moves)
+    if (args.persistent if persistent is None else persistent) != -1:
+        b.set_option("persistent", args.persistent if persistent is None else persistent)
     parts = args.parts if n_parts is None else n_parts
     # initial total energy of every replica (also initialises S(k)): the M2 metric, batched
     b.potential_ewald(as_array=True)
@@ -181,7 +184,20 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None):
     drift = float(np.max(np.abs(energies - tot2["energy"]) / np.abs(energies)))
     b.close()
     return dict(st=st, elapsed=elapsed, t_full=t_full, drift=drift, energy_sum=float(energies.sum()),
-                launches_per_step=st["launches"] / max(shape["steps"], 1))
+                launches_per_step=st["launches"] / max(shape["steps"], 1),
+                server=st["server_steps"] > 0)
+
+
+def launch_mode_roofline(R, a, args, local_rank, g0, barrier, shape, n_mol, box, parts_used):
+    """The move server has no launches to time: the roofline object of a small batch comes from a
+    second, short run of the same batch with a launch per step (persistent = 0)."""
+    sh = dict(shape, steps=min(shape["steps"], 600), warmup=min(shape["warmup"], 60))
+    r_ = measure_moves(R, a, args, local_rank, g0, barrier, sh, persistent=0)
+    rf = roofline_object(r_, R, args, sh, n_mol, box, parts_used)
+    if rf:
+        rf["measured_in"] = "a separate run with a launch per step (persistent = 0)"
+        rf["us_per_step_launch_per_step"] = 1e6 * r_["elapsed"] / sh["steps"]
+    return rf
 
 
 def roofline_object(res, R, args, shape, n_mol, box, parts_used):
@@ -267,6 +283,9 @@ def main():
                     help="1 = the kernel reads host-written records in place (-1 = only below 4096 replicas)")
     ap.add_argument("--device-moves", type=int, default=1,
                     help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
+    ap.add_argument("--persistent", type=int, default=-1,
+                    help="move server for small batches: -1 = library default (up to 64 replicas), "
+                         "0 = a launch per step, 1 = insist")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
@@ -375,7 +394,11 @@ def main():
             "algorithmic_flops": flops_full, "algorithmic_bytes": algorithmic_bytes_full_eval(n_mol),
             "achieved_tflops_per_gpu": flops_full * R / t_full_max / 1e12,
             "frac_fp64_vector_peak_78.6": flops_full * R / t_full_max / 1e12 / FP64_PEAK_TFLOPS}
-        rf = roofline_object(res, R, args, shape, n_mol, box, parts_used)
+        out["config"]["driver"] = ("persistent move server (one kernel per run)" if res["server"]
+                                   else "one launch per step and group")
+        rf = (launch_mode_roofline(R, a, args, local_rank, g0, lambda: torch.cuda.synchronize(),
+                                   shape, n_mol, box, parts_used) if res["server"]
+              else roofline_object(res, R, args, shape, n_mol, box, parts_used))
         if rf:
             out["roofline"] = rf
         # raw work counts: per trial move 2 states x (N_mol - 1) COM tests,
@@ -407,8 +430,12 @@ def main():
                          "steps": sh2["steps"], "groups": sh2["groups"],
                          "energy_drift_rel": r_["drift"],
                          "ns_per_full_energy_eval": 1e9 * r_["t_full"] / r2}
-                rf2 = roofline_object(r_, r2, args, sh2, n_mol, box, default_parts(r2, n_mol))
-                entry["units_per_move"] = default_parts(r2, n_mol)
+                entry["driver"] = ("persistent move server" if r_["server"]
+                                   else "one launch per step and group")
+                rf2 = (launch_mode_roofline(r2, a, args, local_rank, 0, barrier, sh2, n_mol, box,
+                                            default_parts(r2, n_mol)) if r_["server"]
+                       else roofline_object(r_, r2, args, sh2, n_mol, box, default_parts(r2, n_mol)))
+                entry["units_per_move"] = 8 if r_["server"] else default_parts(r2, n_mol)
                 if rf2:
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry

@@ -233,7 +233,21 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      device (counter-based Philox4x32-10 keyed by seed + replica and the step
  *                      number; same move distributions as the host generator, a different random
  *                      stream): only one flag byte per replica and step crosses PCIe and no host
- *                      mirror of the coordinates is kept.  Default 0. */
+ *                      mirror of the coordinates is kept.  Default 0.
+ *   "persistent"       the move server for small batches (device_moves = 1, kernel != 0, no
+ *                      orientations, at most one replica per compute unit): mmc_batch_run /
+ *                      mmc_batch_run_chains launch ONE kernel per call, a workgroup per replica
+ *                      whose waves are the parts of the move; per step the host posts one 8-byte
+ *                      control word per replica in pinned memory (sequence number, result stamp,
+ *                      accept bit of the previous step) and reads one 64-byte result record -- no
+ *                      launch, no copy.  The chain is bit-identical to the launch-per-step driver
+ *                      with n_parts = the server's waves (ceil(molecules / 64) + 1, at most 8, or
+ *                      mmc_run_params.n_parts when > 1).  Every device-side wait is bounded (3 s):
+ *                      a host that stops talking gets MMC_ERR_HIP from the run, not a hung GPU.
+ *                      -1 (default) = use it for up to 64 replicas when it applies, 0 = never,
+ *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
+ *   "server_stall_ms"  test hook: the driver sleeps this long before posting the control words of
+ *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP) */
 int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
 /* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
  * r^2 in (0, 256): lets a test bound its error against an exact evaluation. */
@@ -311,6 +325,8 @@ typedef struct {
     int64_t timed_launches; /* launches that contributed to kernel_ms */
     int64_t torn_records;   /* result records that carried the launch stamp but failed their
                                checksum when first read (re-read until whole) */
+    int64_t server_steps;   /* steps that ran on the persistent move server (option "persistent"):
+                               `launches` then counts control-word posts, not kernel launches */
 } mmc_run_stats;
 
 /* The driver's counter-based generator, exposed for known-answer tests and for callers that

@@ -19,7 +19,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 SOURCES = ["mmc_hip.hip"]
-DEPS = ["mmc_hip.hip", "mmc_host.hpp", "mmc_device.hpp", "mmc_kernels.hpp", "mmc_fast.hpp", "mmc_total.hpp", "mmc_wave.hpp",
+DEPS = ["mmc_hip.hip", "mmc_wave_unit.inc", "mmc_host.hpp", "mmc_device.hpp", "mmc_kernels.hpp", "mmc_fast.hpp", "mmc_total.hpp", "mmc_wave.hpp",
         "mmc_propose.hpp", "mmc_study.hpp", "mmc_system.inc",
         "mmc_ctx.inc", "mmc_batch.inc", "mmc_engine.inc"]
 

@@ -309,10 +309,26 @@ static_assert(sizeof(PartOut) == 64, "PartOut is one 64-byte line");
 // No fence, no event, no stream synchronisation, and the host starts on the first results while
 // the launch still runs.  `w8`: the record as 8 words in LDS, complete before the call.
 #define MMC_STAMP_MASK 0x3fffffffu
+// WRITE_THROUGH = false: plain stores, visible to the host when the L2 writes them back -- at the
+// latest when the kernel ends (a launch-per-step driver needs no more; a write-through store would
+// keep the wave's next s_waitcnt vmcnt waiting for a PCIe round trip).  true: system-scope stores
+// (sc0 sc1), for a persistent kernel whose results the host waits for while it keeps running: a
+// plain store can sit in the L2 for as long as the kernel lives.
+template <bool WRITE_THROUGH = false>
 __device__ inline void store_part(PartOut *dst, const double *w8, int tid)
 {
-    if (tid < 4)
-        reinterpret_cast<double2 *>(dst)[tid] = make_double2(w8[2 * tid], w8[2 * tid + 1]);
+    if (tid < 4) {
+        double2 *p = reinterpret_cast<double2 *>(dst) + tid;
+        if (WRITE_THROUGH) {
+            typedef double part_piece __attribute__((ext_vector_type(2)));
+            part_piece v;
+            v.x = w8[2 * tid];
+            v.y = w8[2 * tid + 1];
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+        } else {
+            *p = make_double2(w8[2 * tid], w8[2 * tid + 1]);
+        }
+    }
 }
 
 // 31-bit checksum of a PartOut's seven sums and its launch stamp (FNV-1a over the 14 dwords with an

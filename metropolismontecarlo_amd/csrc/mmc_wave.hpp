@@ -25,18 +25,20 @@
 // as in every other kernel here; only the summation order differs from k_move_eval_fast.
 #pragma once
 #include "mmc_fast.hpp"
+#include "mmc_propose.hpp"
 
 #define WV_WAVES 4   // waves (= units in flight) per workgroup
 #define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
 #define WV_PF 6      // 64-molecule blocks of the COM scan in flight ahead of the one being tested
 
-struct WaveShared {
+template <int NW> struct WaveSharedT {
     alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
-    cplx ptab[WV_WAVES][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
-    int32_t list[WV_WAVES][WV_LIST];
-    alignas(16) double pvw[WV_WAVES][12];    // pending commit of the unit's replica, record layout
-    alignas(16) double outw[WV_WAVES][8];    // the PartOut being assembled
+    cplx ptab[NW][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
+    int32_t list[NW][WV_LIST];
+    alignas(16) double pvw[NW][12];    // pending commit of the unit's replica, record layout
+    alignas(16) double outw[NW][8];    // the PartOut being assembled
 };
+typedef WaveSharedT<WV_WAVES> WaveShared;
 
 // Diagnostic build (-DWV_STAMPS, scripts/stamps.sh): lane 0 of every unit records the shader clock
 // at the boundaries of its phases into a device array the host reads back (mmc_debug_stamps).
@@ -227,279 +229,12 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
             wave_sync();
         }
 
-        // The seven sums of the unit are reduced and parked in LDS (outw) by the phase that
-        // produces them, so no accumulator is live across phases.
-        double *const outw = sm.outw[wv];
-        unsigned long long ovm0 = 0, ovm1 = 0; // lanes that saw an overlap, old / new state
-
-        // ================= reciprocal part (ewalds.jl:718-826) =================
-        if (do_recip) {
-            double a_rec = 0;
-            // phase tables e^{i 2 pi k x / L}, k = -5..5, of the 3 moved atoms, old and new: 18 rows
-            {
-                const int t = lane < 18 ? lane : 0;
-                const int st = t / 9, q = t - 9 * st; // q = 3 l + d
-                const double x = __shfl(w, (st ? MV_AT_NEW : MV_AT_OLD) + q, 64);
-                if (lane < 18)
-                    phase_row_moderate(x, box, sm.ptab[wv][st][q / 3][q % 3]);
-            }
-            wave_sync();
-            WV_STAMP(2); // phase tables built
-            const double *So = s_buf(bv, r, scur);
-            double *Sn = s_buf(bv, r, scur ^ 1);
-            const int n_it = (nkv + 63) >> 6;
-            // software pipeline: the loads of iteration it + 1 are in flight during iteration it
-            int k = lane;
-            int kp = 0;
-            double cf = 0.0;
-            double2 so = make_double2(0.0, 0.0);
-            if (k < nkv) {
-                kp = kpack[k]; cf = bv.cfac[k];
-                so = *reinterpret_cast<const double2 *>(So + 2 * k);
-            }
-            for (int it = 0; it < n_it; it++) {
-                const int k2 = k + 64;
-                int kp2 = 0;
-                double cf2 = 0.0;
-                double2 so2 = make_double2(0.0, 0.0);
-                if (k2 < nkv) {
-                    kp2 = kpack[k2]; cf2 = bv.cfac[k2];
-                    so2 = *reinterpret_cast<const double2 *>(So + 2 * k2);
-                }
-                if (k < nkv) {
-                    const int kx = kp & 15, ky = (kp >> 4) & 15, kz = (kp >> 8) & 15;
-                    double nr = so.x, ni = so.y;
-#pragma unroll
-                    for (int l = 0; l < 3; l++) {
-                        const cplx tn = c_mul(c_mul(sm.ptab[wv][1][l][0][5 + kx], sm.ptab[wv][1][l][1][ky]),
-                                              sm.ptab[wv][1][l][2][kz]);
-                        const cplx to = c_mul(c_mul(sm.ptab[wv][0][l][0][5 + kx], sm.ptab[wv][0][l][1][ky]),
-                                              sm.ptab[wv][0][l][2][kz]);
-                        nr += fc.q[l] * (tn.re - to.re); // ewalds.jl:805-814
-                        ni += fc.q[l] * (tn.im - to.im);
-                    }
-                    *reinterpret_cast<double2 *>(Sn + 2 * k) = make_double2(nr, ni);
-                    a_rec += cf * ((nr * nr - (-ni) * ni) - (so.x * so.x - (-so.y) * so.y)); // :817-821
-                }
-                k = k2; kp = kp2; cf = cf2; so = so2;
-            }
-            const double s6 = wave_sum(a_rec);
-            if (lane == 0)
-                outw[6] = s6;
-            WV_STAMP(3); // reciprocal loop done
-            wave_sync(); // ptab is rewritten by this wave's next unit
-        } else if (lane == 0) {
-            outw[6] = 0.0;
-        }
-
-        // ================= pair part =================
-        if (do_pairs) {
-            double a_lj0 = 0, a_lj1 = 0, a_v0 = 0, a_v1 = 0, a_q0 = 0, a_q1 = 0;
-            // The chosen molecule stays in the register `w` (lane t = word t of the move record);
-            // its coordinates are pulled into SGPRs with v_readlane where they are used, so only
-            // the six doubles of the current atom a (both states) are live in the pair loop.
-            double cc[2][3]; // centres of mass, st 0 = old, 1 = proposal
-            float ccf[2][3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                cc[0][d] = lane_f64(w, MV_COM_OLD + d);
-                cc[1][d] = lane_f64(w, MV_COM_NEW + d);
-                ccf[0][d] = (float)cc[0][d];
-                ccf[1][d] = (float)cc[1][d];
-            }
-
-            // ---- neighbours list[0 .. cnt): lane n takes neighbour n0 + n ----
-            auto process = [&](int cnt) {
-                wave_sync();
-                for (int n0 = 0; n0 < cnt; n0 += 64) {
-                    const int n = n0 + lane;
-                    const bool act = n < cnt;
-                    const int j = act ? list[n] : 0; // idle lanes: molecule 0, gates forced off
-                    double t[MMC_REC];
-                    const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * MMC_RSTRIDE);
-#pragma unroll
-                    for (int q = 0; q < 6; q++) {
-                        const double2 v = src[q];
-                        t[2 * q] = v.x;
-                        t[2 * q + 1] = v.y;
-                    }
-                    if (n0 == 0)
-                        WV_STAMP(5); // first neighbour records arrived
-                    if (j == pend) {
-#pragma unroll
-                        for (int q = 0; q < MMC_REC; q++)
-                            t[q] = pvw[q];
-                    }
-                    // the gates, exactly: COM minimum image of both states on the reference's
-                    // arithmetic (energy.jl:248-254, ewalds.jl:334-340)
-                    bool g0, g1, l0, l1;
-                    {
-                        const double x0 = vector1D_abs(cc[0][0], t[9], bc), y0 = vector1D_abs(cc[0][1], t[10], bc),
-                                     z0 = vector1D_abs(cc[0][2], t[11], bc);
-                        const double x1 = vector1D_abs(cc[1][0], t[9], bc), y1 = vector1D_abs(cc[1][1], t[10], bc),
-                                     z1 = vector1D_abs(cc[1][2], t[11], bc);
-                        const double c0 = x0 * x0 + y0 * y0 + z0 * z0, c1 = x1 * x1 + y1 * y1 + z1 * z1;
-                        g0 = act && (c0 < pp.qq_gate_sq); // ewalds.jl:340
-                        g1 = act && (c1 < pp.qq_gate_sq);
-                        l0 = same_gate ? g0 : (act && (c0 < pp.lj_gate_sq)); // energy.jl:254
-                        l1 = same_gate ? g1 : (act && (c1 < pp.lj_gate_sq));
-                    }
-                    // one atom pair (a, b), both states.  The Coulomb term needs only r^2, and
-                    // (|d| - L)^2 == (d -+ L)^2 bit for bit, so the minimum image is taken on
-                    // |d| (4 instructions per component instead of 6); the signed vector is
-                    // rebuilt only inside the LJ branch, which few atom pairs enter.
-                    auto pair_ab = [&](int ab, double a0x, double a0y, double a0z, double a1x,
-                                       double a1y, double a1z, double bx, double by, double bz) {
-                        const double qq = fc.qq9[ab];
-                        const bool qneg = qq < 0; // uniform
-                        const double p0x = vector1D_abs(a0x, bx, bc), p0y = vector1D_abs(a0y, by, bc),
-                                     p0z = vector1D_abs(a0z, bz, bc);
-                        const double p1x = vector1D_abs(a1x, bx, bc), p1y = vector1D_abs(a1y, by, bc),
-                                     p1z = vector1D_abs(a1z, bz, bc);
-                        const double u0 = p0x * p0x + p0y * p0y + p0z * p0z;
-                        const double u1 = p1x * p1x + p1y * p1y + p1z * p1z;
-                        const bool ov0 = g0 && qneg && (u0 < pp.ovr); // ewalds.jl:359
-                        const bool ov1 = g1 && qneg && (u1 < pp.ovr);
-                        const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq); // ewalds.jl:362
-                        const bool in1 = g1 && !ov1 && (u1 < pp.qq_slack_sq);
-                        double e0 = qq_table_eval_clamped(sm.qtab, u0);
-                        double e1 = qq_table_eval_clamped(sm.qtab, u1);
-                        // like charges closer than sqrt(ovr): below r^2 = 0.25 the table ends and
-                        // the series takes over (practically never; tested with the compare the
-                        // overlap test has made anyway, UMIN <= ovr)
-                        if (__any(in0 && (u0 < pp.ovr)) || __any(in1 && (u1 < pp.ovr))) {
-                            if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
-                            if (u1 < MMC_QQ_UMIN) e1 = qq_pair_cold(u1, pp.kappa);
-                        }
-                        a_q0 = fma(e0, in0 ? qq : 0.0, a_q0); // ewalds.jl:365-367
-                        a_q1 = fma(e1, in1 ? qq : 0.0, a_q1);
-                        ovm0 |= __ballot(ov0);
-                        ovm1 |= __ballot(ov1);
-                        const double eps = fc.eps9[ab], sg = fc.sig9[ab];
-                        if (eps > 0.001) { // uniform (energy.jl:270); same r^2
-                            if (l0 && u0 < pp.lj_slack_sq) {
-                                const double s2 = sg * sg / u0;
-                                const double s6 = s2 * s2 * s2;
-                                const double s12 = s6 * s6;
-                                const double virab = eps * (2.0 * s12 - s6);
-                                const double f0 = vector1D(a0x, bx, bc) * virab * s2,
-                                             f1 = vector1D(a0y, by, bc) * virab * s2,
-                                             f2 = vector1D(a0z, bz, bc) * virab * s2;
-                                a_lj0 += eps * (s12 - s6);
-                                // COM vector of the virial (energy.jl:248-250, :279-281)
-                                a_v0 += vector1D(cc[0][0], t[9], bc) * f0
-                                        + vector1D(cc[0][1], t[10], bc) * f1
-                                        + vector1D(cc[0][2], t[11], bc) * f2;
-                            }
-                            if (l1 && u1 < pp.lj_slack_sq) {
-                                const double s2 = sg * sg / u1;
-                                const double s6 = s2 * s2 * s2;
-                                const double s12 = s6 * s6;
-                                const double virab = eps * (2.0 * s12 - s6);
-                                const double f0 = vector1D(a1x, bx, bc) * virab * s2,
-                                             f1 = vector1D(a1y, by, bc) * virab * s2,
-                                             f2 = vector1D(a1z, bz, bc) * virab * s2;
-                                a_lj1 += eps * (s12 - s6);
-                                a_v1 += vector1D(cc[1][0], t[9], bc) * f0
-                                        + vector1D(cc[1][1], t[10], bc) * f1
-                                        + vector1D(cc[1][2], t[11], bc) * f2;
-                            }
-                        }
-                    };
-#pragma unroll 1
-                    for (int a = 0; a < 3; a++) {
-                        const double a0x = lane_f64(w, MV_AT_OLD + 3 * a),
-                                     a0y = lane_f64(w, MV_AT_OLD + 3 * a + 1),
-                                     a0z = lane_f64(w, MV_AT_OLD + 3 * a + 2),
-                                     a1x = lane_f64(w, MV_AT_NEW + 3 * a),
-                                     a1y = lane_f64(w, MV_AT_NEW + 3 * a + 1),
-                                     a1z = lane_f64(w, MV_AT_NEW + 3 * a + 2);
-                        // the three b are written out (static register indices) but scheduled one
-                        // after the other: interleaving them costs 40 more VGPRs
-                        pair_ab(3 * a, a0x, a0y, a0z, a1x, a1y, a1z, t[0], t[1], t[2]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        pair_ab(3 * a + 1, a0x, a0y, a0z, a1x, a1y, a1z, t[3], t[4], t[5]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        pair_ab(3 * a + 2, a0x, a0y, a0z, a1x, a1y, a1z, t[6], t[7], t[8]);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-                wave_sync();
-            };
-
-            // ---- COM scan, single-precision prefilter of both states: lane per molecule,
-            // survivors appended to the list in ascending j.  WV_PF blocks of 64 molecules are in
-            // flight ahead of the one being tested (static registers: the body is unrolled WV_PF
-            // times and block b's registers are refilled as soon as it has been tested) ----
-            const float *cfx = bv.comf + (int64_t)r * 3 * bv.cf_stride, *cfy = cfx + bv.cf_stride,
-                        *cfz = cfy + bv.cf_stride;
-            int base = j_begin;
-            while (base < j_end) {
-                int cnt = 0;
-                float fx[WV_PF], fy[WV_PF], fz[WV_PF];
-#pragma unroll
-                for (int b = 0; b < WV_PF; b++) {
-                    const int j = base + 64 * b + lane;
-                    fx[b] = fy[b] = fz[b] = 0.f;
-                    if (j < j_end) { fx[b] = cfx[j]; fy[b] = cfy[j]; fz[b] = cfz[j]; }
-                }
-                while (base < j_end && cnt <= WV_LIST - 64) {
-#pragma unroll
-                    for (int b = 0; b < WV_PF; b++) {
-                        if (base < j_end && cnt <= WV_LIST - 64) { // uniform
-                            const int j = base + lane;
-                            float x = fx[b], y = fy[b], z = fz[b];
-                            {
-                                const int jn = base + 64 * WV_PF + lane; // refill this slot
-                                fx[b] = fy[b] = fz[b] = 0.f;
-                                if (jn < j_end) { fx[b] = cfx[jn]; fy[b] = cfy[jn]; fz[b] = cfz[jn]; }
-                            }
-                            if (pend >= base && pend < base + 64) { // uniform: one block per unit
-                                if (j == pend) { x = (float)pvw[9]; y = (float)pvw[10]; z = (float)pvw[11]; }
-                            }
-                            bool keep = false;
-#pragma unroll
-                            for (int st = 0; st < 2; st++) {
-                                float dx = fabsf(x - ccf[st][0]), dy = fabsf(y - ccf[st][1]),
-                                      dz = fabsf(z - ccf[st][2]);
-                                dx = fminf(dx, boxf - dx);
-                                dy = fminf(dy, boxf - dy);
-                                dz = fminf(dz, boxf - dz);
-                                const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                                keep = keep || (r2 < gatef);
-                            }
-                            keep = keep && (j < j_end) && (j != i0);
-                            const unsigned long long m = __ballot(keep);
-                            if (keep)
-                                list[cnt + lanes_below(m)] = j;
-                            cnt += __popcll(m);
-                            base += 64;
-                        }
-                    }
-                }
-                WV_STAMP(4); // scan done
-                if (cnt)
-                    process(cnt);
-            }
-            WV_STAMP(6); // pair loops done
-            // wave reduction (fixed order: bitwise reproducible)
-            const double s0 = wave_sum(a_lj0), s1 = wave_sum(a_lj1), s2 = wave_sum(a_v0),
-                         s3 = wave_sum(a_v1), s4 = wave_sum(a_q0), s5 = wave_sum(a_q1);
-            if (lane == 0) {
-                outw[0] = s0; outw[1] = s1; outw[2] = s2; outw[3] = s3; outw[4] = s4; outw[5] = s5;
-            }
-        } else if (lane < 6) {
-            outw[lane] = 0.0;
-        }
-
-        // ---- the 64-byte result record ----
-        wave_sync();
-        if (lane == 0)
-            outw[7] = pack_ovl(ovm0 != 0ULL, ovm1 != 0ULL, stamp, part_checksum(outw, stamp));
-        wave_sync();
-        store_part(out + (int64_t)r * n_parts + part, sm.outw[wv], lane);
-        wave_sync();
-        WV_STAMP(7); // result stored
+        // (expanded where they are used: as variables they would be live across the whole unit)
+#define WV_CF_BASE (bv.comf + (int64_t)r * 3 * bv.cf_stride)
+#define WV_PART_DST (out + (int64_t)r * n_parts + part)
+#include "mmc_wave_unit.inc"
+#undef WV_CF_BASE
+#undef WV_PART_DST
     }
 }
 
@@ -724,5 +459,244 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_total_reduce(const TotalPart *par
         t.n_ovl = tot[3] > 0 ? 1 : 0;
         t._pad = 0;
         out[r] = t;
+    }
+}
+
+// =================================================================================================
+// k_move_server_wave -- the wave-per-unit scheme as a PERSISTENT kernel for small replica counts
+// (BASELINE configs[1]: one chain, configs[2]: 32 chains per GPU), where a step is latency: launch
+// + kernel + result poll = 17 us with a launch per step.  Here the kernel is launched once per run,
+// ONE WORKGROUP PER REPLICA: wave w < n_parts - 1 owns pair part w, the last wave the reciprocal
+// part (the part split of k_move_eval_wave, so a chain is bit-identical to the launch-per-step
+// driver with the same n_parts).  Per step
+//   1. every wave draws the proposal of the step itself (the generator of k_propose),
+//      speculatively while the host is still deciding the previous step (legal when n_mol > 1:
+//      step s moves molecule s mod n_mol, which the pending decision does not touch);
+//   2. wave 0 polls the replica's 8-byte control word in pinned host memory (sequence number,
+//      launch stamp, accept bit of the previous step, S-buffer bit, "new step sizes", "quit"),
+//      applies the accepted move to the batch's arrays -- no other workgroup ever touches this
+//      replica's state, and the waves of a workgroup share one L1, so a workgroup barrier is the
+//      whole visibility protocol -- and publishes the word in LDS;
+//   3. the waves evaluate their parts (mmc_wave_unit.inc, the body of k_move_eval_wave) into LDS;
+//      wave 0 adds the parts in the order mmc_combine_parts does and stores ONE 64-byte record
+//      with stamp and checksum: the host consumes it exactly as the single part of a launch.
+// Accept/reject stays on the host.  Every wait is bounded: when wave 0 sees no new control word
+// for SRV_TIMEOUT_TICKS (3 s of the 100 MHz real-time counter) it raises *timeout_flag and the
+// whole workgroup exits, so the grid drains whatever happens to the host.  Workgroups never wait
+// for each other, so residency is not a correctness condition (one workgroup of 8 waves per
+// compute unit fits; the kernel is built for 2 waves per SIMD).
+#define SRV_WAVES 8
+struct ServerArgs {
+    const unsigned long long *ctrl; // pinned host [R]: seq << 40 | (stamp & MMC_STAMP_MASK) << 8 | flags
+    const double2 *steps;           // pinned host [R]: {dr_max, dphi_max}
+    uint64_t seed, replica0;
+    int64_t rng_off;
+    int32_t *timeout_flag;          // pinned host: [0] raised, [1..4] who waited for what
+};
+#define SRV_ACCEPT 1u
+#define SRV_SCUR 2u
+#define SRV_STEPS 4u
+#define SRV_QUIT 8u
+#define SRV_TIMEOUT_TICKS 300000000ULL
+#define SRV_GAVE_UP (~0ULL)
+
+// grid = replicas, block = 64 * n_parts threads (2 <= n_parts <= SRV_WAVES)
+__global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
+    BatchView bv, double *rec, const double *__restrict__ qq_tab,
+    const int32_t *__restrict__ kpack, FastConsts fc, PartOut *out, int n_parts, PairParams pp,
+    ServerArgs sa)
+{
+    __shared__ __align__(16) WaveSharedT<SRV_WAVES> sm;
+    __shared__ __align__(16) double mvw_all[SRV_WAVES][32];
+    __shared__ __align__(16) double comb[8];
+    __shared__ unsigned long long ctl;
+    const int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += blockDim.x)
+        sm.qtab[k] = qq_tab[k];
+    __syncthreads();
+
+    const int n_mol = bv.n_mol, nkv = bv.nkvecs;
+    const double box = bv.box;
+    const BoxConsts bc = box_consts(box);
+    const int np = n_parts - 1;
+    const int plen = (n_mol + np - 1) / np;
+    const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
+    const float boxf = (float)box;
+    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
+    int32_t *const list = sm.list[wv];
+    const double *const pvw = sm.pvw[wv];
+    double *const mvw = mvw_all[wv];
+
+    const int r = blockIdx.x, part = wv;
+    const int unit = r * n_parts + part;
+    (void)unit;
+    const bool do_pairs = part < n_parts - 1;
+    const bool do_recip = part == n_parts - 1;
+    const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
+    const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
+    double *const myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
+    const float *const cf_base = bv.comf + (int64_t)r * 3 * bv.cf_stride;
+    PartOut *const part_dst = out + r;
+    // host memory that changes while the kernel runs: system-scope loads (a plain load may be
+    // served from a cache line fetched at the start of the run)
+    auto load_steps = [&]() {
+        const double *p = reinterpret_cast<const double *>(sa.steps + r);
+        return make_double2(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM),
+                            __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    };
+    double2 sz = load_steps();
+    const ChainKey ck{ sa.seed, (uint32_t)(sa.replica0 + (uint64_t)r) };
+
+    // the move record of step s as a lane-distributed register (lane t = word t), drawn from the
+    // chosen molecule's record: k_propose's rigid generator
+    auto make_proposal = [&](int64_t s) {
+        const int i0p = (int)(s % n_mol);
+        double cur = 0.0;
+        if (lane < MMC_REC)
+            cur = myrec[(int64_t)i0p * MMC_RSTRIDE + lane];
+        double com[3], at[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++) at[q] = lane_f64(cur, q);
+#pragma unroll
+        for (int q = 0; q < 3; q++) com[q] = lane_f64(cur, 9 + q);
+        const MoveXform x = propose_xform(ck, (uint64_t)(sa.rng_off + s), box, sz.x, sz.y, com);
+        if (lane == 0) {
+            MoveRec m;
+            m.mol = i0p + 1;
+            m.flags = 0;
+#pragma unroll
+            for (int q = 0; q < 3; q++) { m.com_new[q] = x.com_new[q]; m.com_old[q] = com[q]; }
+#pragma unroll
+            for (int q = 0; q < 9; q++) m.atoms_old[q] = at[q];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+                apply_xform(x, com, &at[3 * a], &m.atoms_new[3 * a]);
+#pragma unroll
+            for (int q = 0; q < 4; q++) m.q_new[q] = 0.0;
+            const double *mw = reinterpret_cast<const double *>(&m);
+#pragma unroll
+            for (int q = 0; q < MV_WORDS; q++) mvw[q] = mw[q];
+        }
+        wave_sync();
+        double wnew = 0.0;
+        if (lane < MV_WORDS)
+            wnew = mvw[lane];
+        wave_sync();
+        return wnew;
+    };
+
+    double w = make_proposal(0), pw = 0.0;
+#ifdef SRV_PROFILE
+    unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, p0, p1, p2, p3, p4, p5;
+#define SRV_T(x) x = __builtin_amdgcn_s_memrealtime()
+#else
+#define SRV_T(x)
+#endif
+    for (int64_t step = 0;; step++) {
+        asm volatile("" : "+v"(lane)); // as in k_move_eval_wave: keep lane-derived values out of LICM
+        SRV_T(p0);
+        // ---- wave 0: wait for the host's word of this step (bounded), commit, publish ----
+        if (wv == 0) {
+            unsigned long long c = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            for (unsigned spins = 1;; spins++) {
+                unsigned long long v = 0;
+                if (lane == 0)
+                    v = __hip_atomic_load(sa.ctrl + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32)
+                    | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                if ((c >> 40) == (unsigned long long)(step + 1) || (c & SRV_QUIT))
+                    break; // (a host that gives up early posts "quit" with whatever sequence number)
+                if ((spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > SRV_TIMEOUT_TICKS) {
+                    if (lane == 0) { // what this workgroup was waiting for, for the host's message
+                        sa.timeout_flag[1] = r;
+                        sa.timeout_flag[2] = (int32_t)step;
+                        sa.timeout_flag[3] = (int32_t)(c >> 40);
+                        sa.timeout_flag[4] = (int32_t)c;
+                        __hip_atomic_store(sa.timeout_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                    c = SRV_GAVE_UP;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            SRV_T(p1);
+            // the previous step was accepted: commit it (main.jl:598-621)
+            if (c != SRV_GAVE_UP && (c & SRV_ACCEPT) && step > 0) {
+                const int pm = (int)((step - 1) % n_mol);
+                int word = -1; // record word this lane's piece of the previous proposal goes to
+                if (lane >= MV_AT_NEW && lane < MV_AT_NEW + 9) word = lane - MV_AT_NEW;
+                else if (lane >= MV_COM_NEW && lane < MV_COM_NEW + 3) word = 9 + lane - MV_COM_NEW;
+                if (word >= 0) {
+                    myrec[(int64_t)pm * MMC_RSTRIDE + word] = pw;
+                    if (word < 9) {
+                        const int a = word / 3, d = word % 3;
+                        (d == 0 ? bv.ax : d == 1 ? bv.ay : bv.az)[r * bv.atom_stride + 3 * pm + a] = pw;
+                    } else {
+                        const int d = word - 9;
+                        (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pm] = pw;
+                        comf_store(bv, r, pm, d, pw);
+                    }
+                }
+            }
+            if (lane == 0)
+                ctl = c;
+        }
+        __syncthreads(); // the word is published, wave 0's commit stores are complete
+        const unsigned long long c =
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ctl >> 32)) << 32)
+            | (unsigned)__builtin_amdgcn_readfirstlane((int)ctl);
+        if (c == SRV_GAVE_UP)
+            return;
+        const unsigned flags = (unsigned)(c & 0xffu);
+        const unsigned stamp = (unsigned)((c >> 8) & MMC_STAMP_MASK);
+        SRV_T(p2);
+#ifdef SRV_PROFILE
+        if ((flags & SRV_QUIT) && lane == 0 && r == 0)
+            sa.timeout_flag[8 + wv] = (int32_t)pt[2];
+#endif
+        if (flags & SRV_QUIT)
+            break;
+        if (flags & SRV_STEPS)
+            sz = load_steps();
+        if (n_mol == 1 || (flags & SRV_STEPS)) // the speculative proposal is out of date
+            w = make_proposal(step);
+        const int i0 = (int)(step % n_mol);
+        const int scur = (flags & SRV_SCUR) ? 1 : 0;
+        const int pend = -1;
+#define WV_UNIT_NO_STORE
+#define WV_CF_BASE cf_base
+#include "mmc_wave_unit.inc"
+#undef WV_CF_BASE
+#undef WV_UNIT_NO_STORE
+        SRV_T(p3);
+        __syncthreads(); // every part's sums are in sm.outw
+        SRV_T(p4);
+        if (wv == 0) { // mmc_combine_parts' order: ((0 + part 0) + part 1) + ...
+            double v = 0.0;
+            long long ob = 0;
+            for (int q = 0; q < n_parts; q++) {
+                if (lane < 7)
+                    v += sm.outw[q][lane];
+                ob |= __double_as_longlong(sm.outw[q][7]);
+            }
+            if (lane < 7)
+                comb[lane] = v;
+            wave_sync();
+            if (lane == 0)
+                comb[7] = pack_ovl((int)(ob & 1), (int)((ob >> 1) & 1), stamp, part_checksum(comb, stamp));
+            wave_sync();
+            store_part<true>(part_dst, comb, lane);
+        }
+        SRV_T(p5);
+        pw = w;
+        if (n_mol > 1)
+            w = make_proposal(step + 1); // while the host decides this step
+#ifdef SRV_PROFILE
+        pt[0] += p1 - p0; pt[1] += p2 - p1; pt[2] += p3 - p2; pt[3] += p4 - p3; pt[4] += p5 - p4;
+        pt[5] += __builtin_amdgcn_s_memrealtime() - p5;
+#endif
     }
 }

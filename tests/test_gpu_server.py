@@ -1,0 +1,137 @@
+"""The persistent move server (k_move_server_wave, option "persistent") against the launch-per-step
+driver (SURVEY.md section 8 rows a/b: Loop()'s move body, Ewald/main.jl:487-644).
+
+The server evaluates a move with the same part split and the same summation order as a launch with
+n_parts = its waves, draws the same counter-based proposals and leaves accept/reject to the same host
+code, so everything the two drivers return must be IDENTICAL bit for bit: energies, statistics,
+chain records, coordinates and structure factors.  The launch-per-step driver itself is pinned to
+the oracle by test_gpu_batch.py / test_gpu_moves.py."""
+import numpy as np
+import pytest
+
+import common
+from metropolismontecarlo_amd import structs
+from metropolismontecarlo_amd._lib import MMCError
+from metropolismontecarlo_amd.device import Batch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_batch(a, R, persistent, kernel=2):
+    b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+              5.6 / a["box"], structs.factor, 10.0, 10.0)
+    b.set_option("device_moves", 1)
+    b.set_option("kernel", kernel)
+    b.set_option("persistent", persistent)
+    return b
+
+
+def server_waves(n_mol):
+    return min((n_mol + 63) // 64, 7) + 1
+
+
+def state(b):
+    out = []
+    for r in range(b.R):
+        out.extend(b.get_replica(r))
+    return out
+
+
+def same(xs, ys):
+    return len(xs) == len(ys) and all(np.array_equal(x, y) for x, y in zip(xs, ys))
+
+
+@pytest.mark.parametrize("k,R,steps,threads", [(1, 1, 230, 1), (1, 3, 205, 2), (4, 1, 400, 1),
+                                               (4, 32, 160, 2), (2, 5, 60, 3)])
+def test_server_equals_launch_per_step(k, R, steps, threads):
+    """mmc_batch_run twice in a row (the second call continues the random streams and the
+    S-buffer parity of the first), fixed step sizes."""
+    a = common.nist_arrays(k, "unwrapped")
+    P = server_waves(a["com"].shape[0])
+    res = []
+    for persistent in (1, 0):
+        with make_batch(a, R, persistent) as b:
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            stats = []
+            for n in (steps, 37):
+                e, st = b.run(n, 298.15, 0.316555789, 0.05, 11, e, n_groups=min(R, 2), n_parts=P,
+                              n_threads=threads)
+                stats.append([st[q] for q in ("moves", "trans_accept", "rot_accept", "overlaps",
+                                              "trans_attempt", "rot_attempt")])
+            assert st["torn_records"] == 0
+            assert st["launches"] == 37 * min(R, 2)
+            assert st["server_steps"] == (37 if persistent else 0)
+            # the accumulated energy still is the energy of the configuration
+            e2 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e - e2).max() <= 1e-11 * np.abs(e2).max()
+            res.append((e, stats, state(b)))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1] == res[1][1]
+    assert res[0][1][0][1] + res[0][1][0][2] > 0          # something was accepted
+    assert same(res[0][2], res[1][2])
+
+
+def test_server_chains_with_step_adjustment():
+    """mmc_batch_run_chains with Adjust! every sweep (adjust.jl:1-83): the server re-reads the step
+    sizes when told to and re-draws its speculative proposal."""
+    a = common.nist_arrays(1, "unwrapped")
+    n_mol = a["com"].shape[0]
+    P = server_waves(n_mol)
+    res = []
+    for persistent in (1, 0):
+        with make_batch(a, 4, persistent) as b:
+            tot = b.potential_ewald(as_array=True)
+            ch = b.new_chains(tot["energy"], tot["virial"])
+            for n in (3 * n_mol, n_mol + 7):
+                b.run_chains(ch, n, 298.15, seed=21, adjust=True, n_parts=P, n_threads=2)
+            res.append((ch.copy(), state(b)))
+    assert res[0][0].tobytes() == res[1][0].tobytes()
+    assert same(res[0][1], res[1][1])
+    assert len(set(res[0][0]["dr_max"])) > 1 or res[0][0]["dr_max"][0] != 0.15  # steps were adjusted
+
+
+def test_server_default_is_automatic_and_uses_fewer_launches():
+    """persistent = -1 (default): device_moves batches of up to 64 replicas take the server; its
+    runs count one `launch` per step and group all the same (a control-word post)."""
+    a = common.nist_arrays(1, "unwrapped")
+    res = []
+    for persistent in (-1, 1):
+        with make_batch(a, 2, persistent, kernel=3) as b:
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            e, st = b.run(50, 298.15, 0.3, 0.05, 3, e, n_groups=1)
+            assert st["server_steps"] == 50
+            res.append((e, state(b)))
+    assert np.array_equal(res[0][0], res[1][0]) and same(res[0][1], res[1][1])
+
+
+def test_server_refuses_what_it_cannot_do():
+    a = common.nist_arrays(1, "unwrapped")
+    with make_batch(a, 1, 1, kernel=0) as b:      # the generic kernel has no server form
+        e = b.potential_ewald(as_array=True)["energy"].copy()
+        with pytest.raises(MMCError, match="persistent move server needs"):
+            b.run(3, 298.15, 0.3, 0.05, 3, e)
+    with make_batch(a, 1, 1) as b:                 # host-side proposals
+        b.set_option("device_moves", 0)
+        e = b.potential_ewald(as_array=True)["energy"].copy()
+        with pytest.raises(MMCError, match="persistent move server needs"):
+            b.run(3, 298.15, 0.3, 0.05, 3, e)
+        b.set_option("persistent", -1)             # automatic: falls back to launches
+        assert b.run(3, 298.15, 0.3, 0.05, 3, e)[1]["server_steps"] == 0
+
+
+def test_server_wait_is_bounded():
+    """A host that stops talking for longer than the server waits (3 s): the workgroups give up and
+    exit, the run reports it, nothing hangs, and the batch can be loaded again and used."""
+    a = common.nist_arrays(1, "unwrapped")
+    with make_batch(a, 2, 1) as b:
+        e = b.potential_ewald(as_array=True)["energy"].copy()
+        b.set_option("server_stall_ms", 3600)
+        with pytest.raises(MMCError, match="timed out waiting for a control word"):
+            b.run(10, 298.15, 0.3, 0.05, 3, e, n_groups=1)
+        b.set_option("server_stall_ms", 0)
+        for r in range(2):
+            b.set_replica(r, a["com"], a["coords"])
+        e0 = b.potential_ewald(as_array=True)["energy"].copy()
+        assert np.array_equal(e0, e)
+        e1, st = b.run(10, 298.15, 0.3, 0.05, 3, e0, n_groups=1)
+        assert st["moves"] == 20
