@@ -435,7 +435,8 @@ def main():
                 rf2 = (launch_mode_roofline(r2, a, args, local_rank, 0, barrier, sh2, n_mol, box,
                                             default_parts(r2, n_mol)) if r_["server"]
                        else roofline_object(r_, r2, args, sh2, n_mol, box, default_parts(r2, n_mol)))
-                entry["units_per_move"] = 8 if r_["server"] else default_parts(r2, n_mol)
+                entry["units_per_move"] = ((5 if r2 == 1 else 8) if r_["server"]
+                                          else default_parts(r2, n_mol))
                 if rf2:
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry

@@ -241,8 +241,8 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      control word per replica in pinned memory (sequence number, result stamp,
  *                      accept bit of the previous step) and reads one 64-byte result record -- no
  *                      launch, no copy.  The chain is bit-identical to the launch-per-step driver
- *                      with n_parts = the server's waves (ceil(molecules / 64) + 1, at most 8, or
- *                      mmc_run_params.n_parts when > 1).  Every device-side wait is bounded (3 s):
+ *                      with n_parts = the server's waves (ceil(molecules / 64) + 1, at most 8 -- 5 for
+ *                      a single replica -- or mmc_run_params.n_parts when > 1).  Every device-side wait is bounded (3 s):
  *                      a host that stops talking gets MMC_ERR_HIP from the run, not a hung GPU.
  *                      -1 (default) = use it for up to 64 replicas when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
