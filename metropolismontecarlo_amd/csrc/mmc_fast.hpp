@@ -228,7 +228,7 @@ __global__ void k_build_rec(BatchView bv, double *rec, int r)
         o[3 * a] = bv.ax[a0 + a]; o[3 * a + 1] = bv.ay[a0 + a]; o[3 * a + 2] = bv.az[a0 + a];
     }
     o[9] = bv.comx[m0]; o[10] = bv.comy[m0]; o[11] = bv.comz[m0];
-    comf_store(bv, r, j, 0, o[9]); comf_store(bv, r, j, 1, o[10]); comf_store(bv, r, j, 2, o[11]);
+    comq_store(bv, r, j, 0, o[9]); comq_store(bv, r, j, 1, o[10]); comq_store(bv, r, j, 2, o[11]);
 }
 
 // (per_replica = n_mol * MMC_RSTRIDE doubles)
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
         } else {
             const int d = tid - 9;
             (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = v;
-            comf_store(bv, r, pend, d, v);
+            comq_store(bv, r, pend, d, v);
         }
     }
     if (part == 0 && commit && tid >= 12 && tid < 16)
@@ -657,5 +657,5 @@ __global__ void k_settle_rec(BatchView bv, double *rec, const MoveRec *prev,
     const double v = (t < 9) ? prev[r].atoms_new[t] : prev[r].com_new[t - 9];
     rec[((int64_t)r * bv.n_mol + m) * MMC_RSTRIDE + t] = v;
     if (t >= 9)
-        comf_store(bv, r, m, t - 9, v);
+        comq_store(bv, r, m, t - 9, v);
 }

@@ -28,21 +28,46 @@ struct BatchView {
     const int16_t *kmap; // [(nk+1)*(2nk+1)*(2nk+1)] -> k index or -1
     int32_t nkvecs, nk;
     double kappa, factor;
-    // single-precision copy of the centres of mass, SoA [R][3][cf_stride] (homogeneous systems
-    // only, else NULL): the prefilter stream of k_move_eval_wave's COM scan.  Every writer of a
-    // centre of mass keeps it in step through comf_store().
-    float *comf;
-    int64_t cf_stride;
+    // 16-bit fixed-point copy of the centres of mass, SoA [R][3][cq_stride] (homogeneous systems
+    // only, else NULL): q = floor(frac(x / L) * 2^16), the prefilter stream of the COM scans of
+    // k_move_eval_wave / k_total_wave (6 bytes per molecule instead of 24).  A 16-bit difference
+    // wraps exactly as the minimum image does; see com_quant() for the bound that makes the
+    // prefilter a superset of the reference's gate.  Every writer of a centre of mass keeps it in
+    // step through comq_store().
+    uint16_t *comq;
+    int64_t cq_stride;
     // orientation quaternions [R][n_mol][4] (totProps.quat, Ewald/main.jl:527,535,619) or NULL:
     // only kept when the caller asked for the reference's quaternion move generation
     // (mmc_batch_set_orientations); committed together with the coordinates of an accepted move
     double *quat;
 };
 
-__device__ __forceinline__ void comf_store(const BatchView &b, int r, int j, int d, double v)
+// Box-fraction fixed point of one coordinate: floor(frac(x / L) * 65536) mod 65536.  For two
+// coordinates a, b with minimum-image difference d (|d| <= L/2) the wrapped signed 16-bit
+// difference D of their codes satisfies |D| <= |d| / u + 1, u = L / 65536 (a difference of two
+// floors is off by less than 1; the fp64 rounding of x / L adds < 1e-10).  Hence
+// sqrt(Dx^2 + Dy^2 + Dz^2) <= r / u + sqrt(3): com_quant_gate() is a threshold no pair inside the
+// gate can exceed.  (The reference's vector1D wraps once; its distance is never below the true
+// minimum image, so a pair it accepts is accepted here too.)
+__host__ __device__ inline uint16_t com_quant(double x, double inv_box)
 {
-    if (b.comf)
-        b.comf[((int64_t)r * 3 + d) * b.cf_stride + j] = (float)v;
+    double y = x * inv_box;
+    y -= floor(y);
+    return (uint16_t)((uint32_t)(int64_t)(y * 65536.0) & 0xffffu);
+}
+
+// the prefilter threshold on Dx^2 + Dy^2 + Dz^2 (unsigned 32-bit) for a gate of gate_sq A^2
+__host__ __device__ inline uint32_t com_quant_gate(double gate_sq, double box)
+{
+    const double t = sqrt(gate_sq) * 65536.0 / box + 2.6; // sqrt(3) and half a unit of slack per axis
+    const double t2 = t * t;
+    return t2 >= 4294967295.0 ? 0xffffffffu : (uint32_t)t2 + 1u; // (a box below ~2.3 gates: all pass)
+}
+
+__device__ __forceinline__ void comq_store(const BatchView &b, int r, int j, int d, double v)
+{
+    if (b.comq)
+        b.comq[((int64_t)r * 3 + d) * b.cq_stride + j] = com_quant(v, 1.0 / b.box);
 }
 
 __device__ __forceinline__ SysView sys_view(const BatchView &b, int r)
@@ -426,7 +451,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval(BatchView bv, const Mov
         if (rec) // [atoms(9), com(3)] record of the molecule (mmc_fast.hpp)
             rec[((int64_t)r * bv.n_mol + pend) * 16 + (tid < 3 ? 9 + tid : tid - 3)] = *w;
         if (tid < 3)
-            comf_store(bv, r, pend, tid, *w);
+            comq_store(bv, r, pend, tid, *w);
     }
     if (part == 0 && commit && tid >= 12 && tid < 16)
         quat_commit(bv, r, pend, tid - 12, prev[r].q_new[tid - 12], quat_valid(prev[r].q_new));
@@ -518,7 +543,7 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
         o[t] = t < 9 ? a.at[t / 3][t % 3] : a.com[t - 9];
     }
     if (t < 3)
-        comf_store(bv, a.r, a.i0, t, a.com[t]);
+        comq_store(bv, a.r, a.i0, t, a.com[t]);
 }
 
 // Commit the outstanding proposal of every replica whose accept flag is set (main.jl:598-621),

@@ -232,7 +232,7 @@ __global__ void k_rescale(BatchView bv, double *rec, double f)
             o[3 * a] = bv.ax[s]; o[3 * a + 1] = bv.ay[s]; o[3 * a + 2] = bv.az[s];
         }
         o[9] = *c[0]; o[10] = *c[1]; o[11] = *c[2];
-        comf_store(bv, r, j, 0, o[9]); comf_store(bv, r, j, 1, o[10]); comf_store(bv, r, j, 2, o[11]);
+        comq_store(bv, r, j, 0, o[9]); comq_store(bv, r, j, 1, o[10]); comq_store(bv, r, j, 2, o[11]);
     }
 }
 

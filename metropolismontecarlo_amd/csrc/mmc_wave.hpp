@@ -156,11 +156,9 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
     const int np = (n_parts == 1) ? 1 : n_parts - 1;
     const int plen = (n_mol + np - 1) / np;
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
-    // Prefilter threshold.  With c^ = fl32(c): |d^ - d| <= 3 eps L, the fp32 minimum image adds
-    // 2 eps L, so every component is off by at most 5 eps L (eps = 2^-24, |c| <= L), r^2 by at
-    // most 3 L * 5 eps L plus 3 eps L^2 of fp32 rounding = 18 eps L^2; 32 eps L^2 is used.
-    const float boxf = (float)box;
-    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
+    // prefilter of the COM scan: 16-bit box fractions (com_quant, mmc_kernels.hpp)
+    const double inv_box = 1.0 / box;
+    const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
     int32_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
 
@@ -217,7 +215,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
                 } else {
                     const int d = lane - 9;
                     (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = pw;
-                    comf_store(bv, r, pend, d, pw);
+                    comq_store(bv, r, pend, d, pw);
                 }
             }
             if (bv.quat) { // totProps.quat[i] = ei (main.jl:619)
@@ -230,10 +228,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
         }
 
         // (expanded where they are used: as variables they would be live across the whole unit)
-#define WV_CF_BASE (bv.comf + (int64_t)r * 3 * bv.cf_stride)
+#define WV_CQ_BASE (bv.comq + (int64_t)r * 3 * bv.cq_stride)
 #define WV_PART_DST (out + (int64_t)r * n_parts + part)
 #include "mmc_wave_unit.inc"
-#undef WV_CF_BASE
+#undef WV_CQ_BASE
 #undef WV_PART_DST
     }
 }
@@ -273,8 +271,8 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
     const double box = bv.box;
     const BoxConsts bc = box_consts(box);
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
-    const float boxf = (float)box;
-    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
+    const double inv_box = 1.0 / box;
+    const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
     int32_t *const list = sm.list[wv];
 
     for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         asm volatile("" : "+v"(lane)); // see k_move_eval_wave
         const int r = unit / units_per_rep, u = unit - r * units_per_rep;
         const double *myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
-        const float *cfx = bv.comf + (int64_t)r * 3 * bv.cf_stride, *cfy = cfx + bv.cf_stride,
-                    *cfz = cfy + bv.cf_stride;
+        const uint16_t *cqx = bv.comq + (int64_t)r * 3 * bv.cq_stride, *cqy = cqx + bv.cq_stride,
+                       *cqz = cqy + bv.cq_stride;
         double a_lj = 0, a_v = 0, a_q = 0;
         unsigned long long ovm = 0;
 
@@ -379,37 +377,40 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         for (int half = 0; half < (hasB ? 2 : 1); half++) {
             const int i0 = half == 0 ? iA : iB;
             const double w = half == 0 ? wA : wB;
-            float ccf[3];
+            int ccq[3];
+            {
+                const int myq = (lane >= 9 && lane < 12) ? (int)com_quant(w, inv_box) : 0;
 #pragma unroll
-            for (int d = 0; d < 3; d++)
-                ccf[d] = (float)lane_f64(w, 9 + d);
+                for (int d = 0; d < 3; d++)
+                    ccq[d] = lane_i32(myq, 9 + d);
+            }
             // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1
             int base = (i0 + 1) & ~63;
             while (base < n_mol) {
-                float fx[WV_PF], fy[WV_PF], fz[WV_PF];
+                uint32_t fx[WV_PF], fy[WV_PF], fz[WV_PF];
 #pragma unroll
                 for (int b = 0; b < WV_PF; b++) {
                     const int j = base + 64 * b + lane;
-                    fx[b] = fy[b] = fz[b] = 0.f;
-                    if (j < n_mol) { fx[b] = cfx[j]; fy[b] = cfy[j]; fz[b] = cfz[j]; }
+                    fx[b] = fy[b] = fz[b] = 0u;
+                    if (j < n_mol) { fx[b] = cqx[j]; fy[b] = cqy[j]; fz[b] = cqz[j]; }
                 }
                 while (base < n_mol && cnt <= WV_LIST - 64) {
 #pragma unroll
                     for (int b = 0; b < WV_PF; b++) {
                         if (base < n_mol && cnt <= WV_LIST - 64) { // uniform
                             const int j = base + lane;
-                            const float x = fx[b], y = fy[b], z = fz[b];
+                            const uint32_t x = fx[b], y = fy[b], z = fz[b];
                             {
                                 const int jn = base + 64 * WV_PF + lane;
-                                fx[b] = fy[b] = fz[b] = 0.f;
-                                if (jn < n_mol) { fx[b] = cfx[jn]; fy[b] = cfy[jn]; fz[b] = cfz[jn]; }
+                                fx[b] = fy[b] = fz[b] = 0u;
+                                if (jn < n_mol) { fx[b] = cqx[jn]; fy[b] = cqy[jn]; fz[b] = cqz[jn]; }
                             }
-                            float dx = fabsf(x - ccf[0]), dy = fabsf(y - ccf[1]), dz = fabsf(z - ccf[2]);
-                            dx = fminf(dx, boxf - dx);
-                            dy = fminf(dy, boxf - dy);
-                            dz = fminf(dz, boxf - dz);
-                            const float r2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                            const bool keep = (r2 < gatef) && (j < n_mol) && (j > i0);
+                            const int dx = (int16_t)(uint16_t)(x - (uint32_t)ccq[0]),
+                                      dy = (int16_t)(uint16_t)(y - (uint32_t)ccq[1]),
+                                      dz = (int16_t)(uint16_t)(z - (uint32_t)ccq[2]);
+                            const uint32_t r2 = (uint32_t)(dx * dx) + (uint32_t)(dy * dy)
+                                                + (uint32_t)(dz * dz);
+                            const bool keep = (r2 < gate_q) && (j < n_mol) && (j > i0);
                             const unsigned long long m = __ballot(keep);
                             if (keep)
                                 list[cnt + lanes_below(m)] = j | (half << 27);
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
     const int np = n_parts - 1;
     const int plen = (n_mol + np - 1) / np;
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
-    const float boxf = (float)box;
-    const float gatef = (float)(fmax(pp.lj_gate_sq, pp.qq_gate_sq) + 32.0 * 0x1.0p-24 * box * box);
+    const double inv_box = 1.0 / box;
+    const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
     int32_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
     double *const mvw = mvw_all[wv];
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
     const int j_begin = do_pairs ? min(part * plen, n_mol) : 0;
     const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
     double *const myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
-    const float *const cf_base = bv.comf + (int64_t)r * 3 * bv.cf_stride;
+    const uint16_t *const cq_base = bv.comq + (int64_t)r * 3 * bv.cq_stride;
     PartOut *const part_dst = out + r;
     // host memory that changes while the kernel runs: system-scope loads (a plain load may be
     // served from a cache line fetched at the start of the run)
@@ -637,7 +638,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
                     } else {
                         const int d = word - 9;
                         (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pm] = pw;
-                        comf_store(bv, r, pm, d, pw);
+                        comq_store(bv, r, pm, d, pw);
                     }
                 }
             }
@@ -667,9 +668,9 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
         const int scur = (flags & SRV_SCUR) ? 1 : 0;
         const int pend = -1;
 #define WV_UNIT_NO_STORE
-#define WV_CF_BASE cf_base
+#define WV_CQ_BASE cq_base
 #include "mmc_wave_unit.inc"
-#undef WV_CF_BASE
+#undef WV_CQ_BASE
 #undef WV_UNIT_NO_STORE
         SRV_T(p3);
         __syncthreads(); // every part's sums are in sm.outw

@@ -157,3 +157,19 @@ def test_block_line_is_the_references_format():
     # no attempt yet: Julia prints NaN for 0/0
     c["rot_attempt"] = c["rot_naccept"] = 0
     assert "Ratio rot:  nan" in block_line(c[0], blk, n_mol, box).replace("NaN", "nan").replace("-nan", " nan")
+
+
+def test_fixed_point_code_properties():
+    """com_quant (csrc/mmc_kernels.hpp) restated in numpy: the wrapped 16-bit difference of two
+    box-fraction codes exceeds the minimum-image distance by less than one unit per axis, which is
+    what com_quant_gate's threshold relies on (the device side is tests/test_gpu_prefilter.py)."""
+    rng = np.random.default_rng(0)
+    L = 30.0
+    x = rng.random((20000, 3)) * 3 * L - L
+    y = x + (rng.random((20000, 3)) - 0.5) * L * 0.999       # |minimum image| < L / 2
+    q = lambda v: (np.floor((v / L - np.floor(v / L)) * 65536.0).astype(np.int64)) & 0xFFFF
+    D = ((q(x) - q(y) + 32768) % 65536) - 32768
+    d = x - y
+    d -= L * np.rint(d / L)
+    u = L / 65536.0
+    assert (np.abs(D) <= np.abs(d) / u + 1.0 + 1e-9).all()
