@@ -28,12 +28,14 @@ struct BatchView {
     const int16_t *kmap; // [(nk+1)*(2nk+1)*(2nk+1)] -> k index or -1
     int32_t nkvecs, nk;
     double kappa, factor;
-    // 16-bit fixed-point copy of the centres of mass, SoA [R][3][cq_stride] (homogeneous systems
-    // only, else NULL): q = floor(frac(x / L) * 2^16), the prefilter stream of the COM scans of
-    // k_move_eval_wave / k_total_wave (6 bytes per molecule instead of 24).  A 16-bit difference
-    // wraps exactly as the minimum image does; see com_quant() for the bound that makes the
-    // prefilter a superset of the reference's gate.  Every writer of a centre of mass keeps it in
-    // step through comq_store().
+    // 16-bit fixed-point copy of the centres of mass (homogeneous systems only, else NULL):
+    // q = floor(frac(x / L) * 2^16) per axis, the prefilter stream of the COM scans of
+    // k_move_eval_wave / k_total_wave (6 bytes per molecule instead of 24).  Per replica
+    // 3 * cq_stride codes: (x, y) pairs of molecule j at [2 j], [2 j + 1] -- one 32-bit load, one
+    // packed 16-bit subtract -- then the z codes from [2 * cq_stride].  A 16-bit difference wraps
+    // exactly as the minimum image does; see com_quant() for the bound that makes the prefilter a
+    // superset of the reference's gate.  Every writer of a centre of mass keeps it in step through
+    // comq_store().
     uint16_t *comq;
     int64_t cq_stride;
     // orientation quaternions [R][n_mol][4] (totProps.quat, Ewald/main.jl:527,535,619) or NULL:
@@ -64,10 +66,24 @@ __host__ __device__ inline uint32_t com_quant_gate(double gate_sq, double box)
     return t2 >= 4294967295.0 ? 0xffffffffu : (uint32_t)t2 + 1u; // (a box below ~2.3 gates: all pass)
 }
 
+// One prefilter test: codes (x | y << 16, z) of a molecule against those of a chosen centre of
+// mass; returns Dx^2 + Dy^2 + Dz^2 (5 instructions: v_pk_sub_i16, v_sub, v_mul_i32_i24 on the
+// sign-extended half, v_dot2c_i32_i16).
+typedef short mmc_s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short mmc_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t com_quant_dist2(uint32_t xy, uint32_t z, uint32_t cxy, uint32_t cz)
+{
+    const mmc_u16x2 d = __builtin_bit_cast(mmc_u16x2, xy) - __builtin_bit_cast(mmc_u16x2, cxy);
+    const int dz = (int16_t)(uint16_t)(z - cz);
+    const mmc_s16x2 ds = __builtin_bit_cast(mmc_s16x2, d);
+    return (uint32_t)__builtin_amdgcn_sdot2(ds, ds, dz * dz, false);
+}
+
 __device__ __forceinline__ void comq_store(const BatchView &b, int r, int j, int d, double v)
 {
     if (b.comq)
-        b.comq[((int64_t)r * 3 + d) * b.cq_stride + j] = com_quant(v, 1.0 / b.box);
+        b.comq[(int64_t)r * 3 * b.cq_stride + (d < 2 ? 2 * j + d : 2 * b.cq_stride + j)] =
+            com_quant(v, 1.0 / b.box);
 }
 
 __device__ __forceinline__ SysView sys_view(const BatchView &b, int r)

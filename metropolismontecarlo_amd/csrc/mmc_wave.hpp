@@ -27,9 +27,21 @@
 #include "mmc_fast.hpp"
 #include "mmc_propose.hpp"
 
+#ifndef WV_WAVES
 #define WV_WAVES 4   // waves (= units in flight) per workgroup
-#define WV_LIST 256  // neighbour-list slots per wave; the scan flushes when fewer than 64 are free
+#endif
+#ifndef WV_OCC
+#define WV_OCC 4     // waves per SIMD k_move_eval_wave is compiled for
+#endif
+#ifndef WV_LIST
+#define WV_LIST 640  // neighbour-list slots per wave; the scan empties it when fewer than 64 WV_PF are free
+#endif
+#ifndef WV_PF
 #define WV_PF 6      // 64-molecule blocks of the COM scan in flight ahead of the one being tested
+#endif
+#ifndef WV_TPF
+#define WV_TPF 3     // ... in k_total_wave, whose scans are 6 blocks long on average (4: spills at 96 VGPRs)
+#endif
 
 template <int NW> struct WaveSharedT {
     alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
@@ -136,7 +148,7 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
 // g * WV_WAVES + w, + gridDim.x * WV_WAVES, ...  Unit u = (replica r_base + u / n_parts,
 // part u % n_parts); part semantics as k_move_eval (the last part of n_parts > 1 does the
 // reciprocal part, the others split the molecule range).
-__global__ __launch_bounds__(WV_WAVES * 64, 4) void k_move_eval_wave(
+__global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
     const MoveRec *__restrict__ prev, PartOut *out, int n_parts, PairParams pp, int r_base,
@@ -280,8 +292,9 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         asm volatile("" : "+v"(lane)); // see k_move_eval_wave
         const int r = unit / units_per_rep, u = unit - r * units_per_rep;
         const double *myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
-        const uint16_t *cqx = bv.comq + (int64_t)r * 3 * bv.cq_stride, *cqy = cqx + bv.cq_stride,
-                       *cqz = cqy + bv.cq_stride;
+        const uint16_t *cq0 = bv.comq + (int64_t)r * 3 * bv.cq_stride;
+        const uint32_t *sxy = reinterpret_cast<const uint32_t *>(cq0);
+        const uint16_t *sz = cq0 + 2 * bv.cq_stride;
         double a_lj = 0, a_v = 0, a_q = 0;
         unsigned long long ovm = 0;
 
@@ -377,49 +390,40 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         for (int half = 0; half < (hasB ? 2 : 1); half++) {
             const int i0 = half == 0 ? iA : iB;
             const double w = half == 0 ? wA : wB;
-            int ccq[3];
+            uint32_t cqxy, cqz; // this molecule's codes, x | y << 16 and z
             {
                 const int myq = (lane >= 9 && lane < 12) ? (int)com_quant(w, inv_box) : 0;
-#pragma unroll
-                for (int d = 0; d < 3; d++)
-                    ccq[d] = lane_i32(myq, 9 + d);
+                cqxy = (uint32_t)lane_i32(myq, 9) | (uint32_t)lane_i32(myq, 10) << 16;
+                cqz = (uint32_t)lane_i32(myq, 11);
             }
-            // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1
+            // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1, WV_TPF of
+            // them per trip with no branch around a load (see mmc_wave_unit.inc); blocks past the
+            // last molecule test clamped, masked lanes
             int base = (i0 + 1) & ~63;
+            uint32_t fxy[WV_TPF], fz[WV_TPF];
+#pragma unroll
+            for (int b = 0; b < WV_TPF; b++) {
+                const int j = min(base + 64 * b + lane, n_mol - 1);
+                fxy[b] = sxy[j]; fz[b] = sz[j];
+            }
             while (base < n_mol) {
-                uint32_t fx[WV_PF], fy[WV_PF], fz[WV_PF];
 #pragma unroll
-                for (int b = 0; b < WV_PF; b++) {
-                    const int j = base + 64 * b + lane;
-                    fx[b] = fy[b] = fz[b] = 0u;
-                    if (j < n_mol) { fx[b] = cqx[j]; fy[b] = cqy[j]; fz[b] = cqz[j]; }
-                }
-                while (base < n_mol && cnt <= WV_LIST - 64) {
-#pragma unroll
-                    for (int b = 0; b < WV_PF; b++) {
-                        if (base < n_mol && cnt <= WV_LIST - 64) { // uniform
-                            const int j = base + lane;
-                            const uint32_t x = fx[b], y = fy[b], z = fz[b];
-                            {
-                                const int jn = base + 64 * WV_PF + lane;
-                                fx[b] = fy[b] = fz[b] = 0u;
-                                if (jn < n_mol) { fx[b] = cqx[jn]; fy[b] = cqy[jn]; fz[b] = cqz[jn]; }
-                            }
-                            const int dx = (int16_t)(uint16_t)(x - (uint32_t)ccq[0]),
-                                      dy = (int16_t)(uint16_t)(y - (uint32_t)ccq[1]),
-                                      dz = (int16_t)(uint16_t)(z - (uint32_t)ccq[2]);
-                            const uint32_t r2 = (uint32_t)(dx * dx) + (uint32_t)(dy * dy)
-                                                + (uint32_t)(dz * dz);
-                            const bool keep = (r2 < gate_q) && (j < n_mol) && (j > i0);
-                            const unsigned long long m = __ballot(keep);
-                            if (keep)
-                                list[cnt + lanes_below(m)] = j | (half << 27);
-                            cnt += __popcll(m);
-                            base += 64;
-                        }
+                for (int b = 0; b < WV_TPF; b++) {
+                    const int j = base + lane;
+                    const uint32_t xy = fxy[b], z = fz[b];
+                    {
+                        const int jn = min(base + 64 * WV_TPF + lane, n_mol - 1);
+                        fxy[b] = sxy[jn]; fz[b] = sz[jn];
                     }
+                    const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q) && (j < n_mol)
+                                      && (j > i0);
+                    const unsigned long long m = __ballot(keep);
+                    if (keep)
+                        list[cnt + lanes_below(m)] = j | (half << 27);
+                    cnt += __popcll(m);
+                    base += 64;
                 }
-                if (cnt > WV_LIST - 64) { // the list is full: empty it and go on scanning
+                if (cnt > WV_LIST - 64 * WV_TPF) { // no room for another trip: empty the list
                     process(cnt);
                     cnt = 0;
                 }
