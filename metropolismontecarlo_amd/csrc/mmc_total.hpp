@@ -252,6 +252,132 @@ __global__ void k_atom_phases(BatchView bv, double *ph)
     sincos(MMC_TWOPI * bv.az[a] / L, &sn, &cs); o[4] = cs; o[5] = sn;
 }
 
+// RecipLong for large batches with the whole replica in LDS: one workgroup of RL_WAVES waves per
+// replica builds the six phase factors of every atom (k_atom_phases' arithmetic) and its charge in
+// LDS -- 56 bytes per atom, 126 KB at 2250 atoms, which MI355X's 160 KB per compute unit holds --
+// and every wave then walks all atoms once per (kx, ky) column it takes from a shared queue
+// (columns in descending order of work, so the waves finish together), exactly as a 64-thread
+// workgroup of k_recip_long_ph<64> does: same per-lane sums, same wave reduction, same S(k) bit
+// for bit.  The kz of a column are the symmetric range 5 - M .. 5 + M (k^2 < k_sq_max), so the
+// inner loop is compiled for each M instead of testing every kz of every atom; and the phase
+// array never exists in memory.
+#define RL_WAVES 16
+struct RecipOrder {
+    uint8_t col[6 * MMC_NKTAB]; // column indices kx * 11 + ky + 5, most work first
+    int32_t n;                  // columns that have any k-vector
+};
+
+template <int M>
+__device__ __noinline__ void recip_column_lds(const BatchView &bv, const double *ph, const double *qv,
+                                                 int n_atoms, int r, int kx, int ky, int lane)
+{
+    const int aky = ky < 0 ? -ky : ky;
+    double acc[2 * (2 * M + 1)];
+#pragma unroll
+    for (int k = 0; k < 2 * (2 * M + 1); k++)
+        acc[k] = 0.0;
+    for (int l = lane; l < n_atoms; l += 64) {
+        const double q = qv[l];
+        const double2 px = *reinterpret_cast<const double2 *>(ph + 6 * l),
+                      py = *reinterpret_cast<const double2 *>(ph + 6 * l + 2),
+                      pz = *reinterpret_cast<const double2 *>(ph + 6 * l + 4);
+        const cplx x1 = { px.x, px.y }, y1 = { py.x, py.y }, z1 = { pz.x, pz.y };
+        cplx ex = { 1.0, 0.0 }, ey = { 1.0, 0.0 };
+        if (kx > 0) {
+            ex = x1;
+            for (int k = 2; k <= kx; k++)
+                ex = c_mul(ex, x1);
+        }
+        if (aky > 0) {
+            ey = y1;
+            for (int k = 2; k <= aky; k++)
+                ey = c_mul(ey, y1);
+            if (ky < 0)
+                ey = c_conj(ey);
+        }
+        cplx ez[2 * M + 1]; // kz = -M .. M at index kz + M (ewalds.jl:575-585)
+        const cplx one = { 1.0, 0.0 };
+        ez[M] = one; ez[M + 1] = z1; ez[M - 1] = c_conj(z1);
+        cplx p = z1;
+#pragma unroll
+        for (int k = 2; k <= M; k++) {
+            p = c_mul(p, z1);
+            ez[M + k] = p;
+            ez[M - k] = c_conj(p);
+        }
+        const cplx qxy = c_mul(c_rmul(q, ex), ey);
+#pragma unroll
+        for (int k = 0; k < 2 * M + 1; k++) {
+            const cplx t = c_mul(qxy, ez[k]);
+            acc[2 * k] += t.re;
+            acc[2 * k + 1] += t.im;
+        }
+    }
+    double tot[2 * (2 * M + 1)];
+#pragma unroll
+    for (int k = 0; k < 2 * (2 * M + 1); k++)
+        tot[k] = wave_sum(acc[k]);
+    if (lane == 0) {
+        const int16_t *col = bv.kmap + (kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB;
+        double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
+#pragma unroll
+        for (int k = 0; k < 2 * M + 1; k++) {
+            const int idx = col[5 - M + k];
+            if (idx >= 0) {
+                s0[2 * idx] = tot[2 * k]; s0[2 * idx + 1] = tot[2 * k + 1];
+                s1[2 * idx] = tot[2 * k]; s1[2 * idx + 1] = tot[2 * k + 1];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(RL_WAVES * 64) void k_recip_long_lds(BatchView bv, RecipOrder order)
+{
+    extern __shared__ __align__(16) double rl_lds[];
+    __shared__ int next_col;
+    const int n_atoms = bv.n_atoms;
+    double *ph = rl_lds;               // [n_atoms][6] cos x, sin x, cos y, sin y, cos z, sin z
+    double *qv = rl_lds + 6 * n_atoms; // [n_atoms]
+    const int r = blockIdx.x;
+    const double L = bv.box;
+    if (threadIdx.x == 0)
+        next_col = 0;
+    for (int l = threadIdx.x; l < n_atoms; l += RL_WAVES * 64) {
+        const int64_t a = r * bv.atom_stride + l;
+        double sn, cs;
+        sincos(MMC_TWOPI * bv.ax[a] / L, &sn, &cs); ph[6 * l] = cs; ph[6 * l + 1] = sn;
+        sincos(MMC_TWOPI * bv.ay[a] / L, &sn, &cs); ph[6 * l + 2] = cs; ph[6 * l + 3] = sn;
+        sincos(MMC_TWOPI * bv.az[a] / L, &sn, &cs); ph[6 * l + 4] = cs; ph[6 * l + 5] = sn;
+        qv[l] = bv.charge[l];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (;;) {
+        int slot = 0;
+        if (lane == 0)
+            slot = atomicAdd(&next_col, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= order.n)
+            break;
+        const int c = order.col[slot];
+        const int kx = c / MMC_NKTAB, ky = c % MMC_NKTAB - 5;
+        // the kz of this column: 5 - m .. 5 + m, and within it exactly those with an index
+        const int16_t *col = bv.kmap + c * MMC_NKTAB;
+        int m = 0;
+        for (int k = 0; k <= 5; k++)
+            if (col[5 + k] >= 0 || col[5 - k] >= 0)
+                m = k;
+        switch (m) {
+        case 0: // only kz = 0
+        case 1: recip_column_lds<1>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        case 2: recip_column_lds<2>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        case 3: recip_column_lds<3>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        case 4: recip_column_lds<4>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        default: recip_column_lds<5>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        }
+    }
+}
+
 // k_recip_long with the phases read instead of recomputed per (kx, ky) column.
 // grid (66 columns, R, n_chunks): with n_chunks > 1 (few replicas: the 66 workgroups of one
 // system would leave most of the chip idle and walk all atoms serially) chunk c sums atoms
