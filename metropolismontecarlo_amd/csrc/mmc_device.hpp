@@ -116,6 +116,41 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// sin and cos of a moderate angle (here 2 pi c / L with c within a few box lengths): quadrant
+// reduction by a two-part pi/2 (Cody-Waite: n * pio2_1 is exact for n < 2^20, so the reduction
+// holds its 1e-16 absolute accuracy up to |x| ~ 8e5) and the fdlibm kernel polynomials on
+// |r| <= pi/4 (< 1 ulp each) -- the accuracy class of the libm sin/cos the reference calls, in
+// ~45 instructions and 16 registers instead of ocml's ~200 / 60 (whose Payne-Hanek path for huge
+// arguments is what costs).  An atom more than 1e5 box lengths outside its box is first folded
+// back by whole periods, at the accuracy such a coordinate has left.
+__device__ __forceinline__ void sincos_moderate(double x, double &sn, double &cs)
+{
+    if (!(fabs(x) < 8.0e5))
+        x = fma(-6.283185307179586, rint(x * 0.15915494309189535), x);
+    const double fn = rint(x * 6.36619772367581382433e-01);          // x * 2/pi
+    double r = fma(-fn, 1.57079632673412561417e+00, x);              // pio2_1 (33 bits)
+    r = fma(-fn, 6.07710050650619224932e-11, r);                     // pio2_1t
+    const int n = (int)fn;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;                           // S6
+    ps = fma(ps, z, -2.50507602534068634195e-08);
+    ps = fma(ps, z, 2.75573137070700676789e-06);
+    ps = fma(ps, z, -1.98412698298579493134e-04);
+    ps = fma(ps, z, 8.33333333332248946124e-03);
+    ps = fma(ps, z, -1.66666666666666324348e-01);                     // S1
+    const double s = fma(z * r, ps, r);
+    double pc = -1.13596475577881948265e-11;                          // C6
+    pc = fma(pc, z, 2.08757232129817482790e-09);
+    pc = fma(pc, z, -2.75573143513906633035e-07);
+    pc = fma(pc, z, 2.48015872894767294178e-05);
+    pc = fma(pc, z, -1.38888888888741095749e-03);
+    pc = fma(pc, z, 4.16666666666666019037e-02);                      // C1
+    const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
+    sn = (n & 2) ? -a : a;
+    cs = ((n + 1) & 2) ? -b : b;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll

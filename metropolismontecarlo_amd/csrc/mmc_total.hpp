@@ -247,9 +247,9 @@ __global__ void k_atom_phases(BatchView bv, double *ph)
     const int64_t a = r * bv.atom_stride + l;
     double *o = ph + ((int64_t)r * bv.n_atoms + l) * 6;
     double sn, cs;
-    sincos(MMC_TWOPI * bv.ax[a] / L, &sn, &cs); o[0] = cs; o[1] = sn;
-    sincos(MMC_TWOPI * bv.ay[a] / L, &sn, &cs); o[2] = cs; o[3] = sn;
-    sincos(MMC_TWOPI * bv.az[a] / L, &sn, &cs); o[4] = cs; o[5] = sn;
+    sincos_moderate(MMC_TWOPI * bv.ax[a] / L, sn, cs); o[0] = cs; o[1] = sn;
+    sincos_moderate(MMC_TWOPI * bv.ay[a] / L, sn, cs); o[2] = cs; o[3] = sn;
+    sincos_moderate(MMC_TWOPI * bv.az[a] / L, sn, cs); o[4] = cs; o[5] = sn;
 }
 
 // RecipLong for large batches with the whole replica in LDS: one workgroup of RL_WAVES waves per
@@ -345,9 +345,9 @@ __global__ __launch_bounds__(RL_WAVES * 64) void k_recip_long_lds(BatchView bv, 
     for (int l = threadIdx.x; l < n_atoms; l += RL_WAVES * 64) {
         const int64_t a = r * bv.atom_stride + l;
         double sn, cs;
-        sincos(MMC_TWOPI * bv.ax[a] / L, &sn, &cs); ph[6 * l] = cs; ph[6 * l + 1] = sn;
-        sincos(MMC_TWOPI * bv.ay[a] / L, &sn, &cs); ph[6 * l + 2] = cs; ph[6 * l + 3] = sn;
-        sincos(MMC_TWOPI * bv.az[a] / L, &sn, &cs); ph[6 * l + 4] = cs; ph[6 * l + 5] = sn;
+        sincos_moderate(MMC_TWOPI * bv.ax[a] / L, sn, cs); ph[6 * l] = cs; ph[6 * l + 1] = sn;
+        sincos_moderate(MMC_TWOPI * bv.ay[a] / L, sn, cs); ph[6 * l + 2] = cs; ph[6 * l + 3] = sn;
+        sincos_moderate(MMC_TWOPI * bv.az[a] / L, sn, cs); ph[6 * l + 4] = cs; ph[6 * l + 5] = sn;
         qv[l] = bv.charge[l];
     }
     __syncthreads();
