@@ -116,6 +116,17 @@ __device__ __forceinline__ int lanes_below(unsigned long long mask)
                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
 }
 
+// Lane masks straight from the compare's SGPR pair.  HIP's __ballot / __any go through an integer
+// (v_cndmask 0/1, v_cmp_ne): two VALU instructions per use, 8 % of an atom-pair evaluation.
+__device__ __forceinline__ unsigned long long wave_ballot(bool p)
+{
+    return __builtin_amdgcn_ballot_w64(p);
+}
+__device__ __forceinline__ bool wave_any(bool p)
+{
+    return __builtin_amdgcn_ballot_w64(p) != 0ULL;
+}
+
 // sin and cos of a moderate angle (here 2 pi c / L with c within a few box lengths): quadrant
 // reduction by a two-part pi/2 (Cody-Waite: n * pio2_1 is exact for n < 2^20, so the reduction
 // holds its 1e-16 absolute accuracy up to |x| ~ 8e5) and the fdlibm kernel polynomials on

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         const uint32_t *sxy = reinterpret_cast<const uint32_t *>(cq0);
         const uint16_t *sz = cq0 + 2 * bv.cq_stride;
         double a_lj = 0, a_v = 0, a_q = 0;
-        unsigned long long ovm = 0;
+        bool ovl = false; // per-lane overlap flag (a lane mask in SGPRs), one ballot per unit
 
         // The unit's two molecules as lane-distributed records (lane t = word t); the neighbours
         // of both go into ONE list, tagged with the molecule they belong to, so that the pair
@@ -316,11 +316,11 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
                     const bool ov0 = g0 && qneg && (u0 < pp.ovr);          // ewalds.jl:359
                     const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq);  // ewalds.jl:362
                     double e0 = qq_table_eval_clamped(sm.qtab, u0);
-                    if (__any(in0 && (u0 < pp.ovr))) {
+                    if (wave_any(in0 && (u0 < pp.ovr))) {
                         if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
                     }
                     a_q = fma(e0, in0 ? qq : 0.0, a_q);
-                    ovm |= __ballot(ov0);
+                    ovl = ovl || ov0;
                     const double eps = fc.eps9[ab], sg = fc.sig9[ab];
                     if (eps > 0.001) { // uniform (energy.jl:270)
                         if (l0 && u0 < pp.lj_slack_sq) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
                     }
                     const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q) && (j < n_mol)
                                       && (j > i0);
-                    const unsigned long long m = __ballot(keep);
+                    const unsigned long long m = wave_ballot(keep);
                     if (keep)
                         list[cnt + lanes_below(m)] = j | (half << 27);
                     cnt += __popcll(m);
@@ -397,10 +397,11 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         if (cnt)
             process(cnt);
         const double s0 = wave_sum(a_lj), s1 = wave_sum(a_v), s2 = wave_sum(a_q);
+        const bool any_ovl = wave_any(ovl); // (all lanes: a ballot)
         if (lane == 0) {
             TotalPart o;
             o.lj_pot = s0; o.lj_vir = s1; o.qq = s2;
-            o.n_ovl = ovm != 0ULL ? 1 : 0;
+            o.n_ovl = any_ovl ? 1 : 0;
             o._pad = 0;
             out[unit] = o;
         }
