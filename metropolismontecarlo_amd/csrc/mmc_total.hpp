@@ -268,9 +268,10 @@ struct RecipOrder {
 };
 
 template <int M>
-__device__ __noinline__ void recip_column_lds(const BatchView &bv, const double *ph, const double *qv,
-                                                 int n_atoms, int r, int kx, int ky, int lane)
-{
+__device__ __noinline__ void recip_column_lds(const int16_t *col, double *s0, double *s1, const double *ph,
+                                             const double *qv, int n_atoms, int kx, int ky, int lane)
+{   // (plain pointers, not the BatchView: a struct passed by reference to a function that is not
+    // inlined is copied to scratch by every thread)
     const int aky = ky < 0 ? -ky : ky;
     double acc[2 * (2 * M + 1)];
 #pragma unroll
@@ -318,8 +319,6 @@ __device__ __noinline__ void recip_column_lds(const BatchView &bv, const double 
     for (int k = 0; k < 2 * (2 * M + 1); k++)
         tot[k] = wave_sum(acc[k]);
     if (lane == 0) {
-        const int16_t *col = bv.kmap + (kx * MMC_NKTAB + (ky + 5)) * MMC_NKTAB;
-        double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
 #pragma unroll
         for (int k = 0; k < 2 * M + 1; k++) {
             const int idx = col[5 - M + k];
@@ -367,13 +366,14 @@ __global__ __launch_bounds__(RL_WAVES * 64) void k_recip_long_lds(BatchView bv, 
         for (int k = 0; k <= 5; k++)
             if (col[5 + k] >= 0 || col[5 - k] >= 0)
                 m = k;
+        double *s0 = s_buf(bv, r, 0), *s1 = s_buf(bv, r, 1);
         switch (m) {
         case 0: // only kz = 0
-        case 1: recip_column_lds<1>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
-        case 2: recip_column_lds<2>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
-        case 3: recip_column_lds<3>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
-        case 4: recip_column_lds<4>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
-        default: recip_column_lds<5>(bv, ph, qv, n_atoms, r, kx, ky, lane); break;
+        case 1: recip_column_lds<1>(col, s0, s1, ph, qv, n_atoms, kx, ky, lane); break;
+        case 2: recip_column_lds<2>(col, s0, s1, ph, qv, n_atoms, kx, ky, lane); break;
+        case 3: recip_column_lds<3>(col, s0, s1, ph, qv, n_atoms, kx, ky, lane); break;
+        case 4: recip_column_lds<4>(col, s0, s1, ph, qv, n_atoms, kx, ky, lane); break;
+        default: recip_column_lds<5>(col, s0, s1, ph, qv, n_atoms, kx, ky, lane); break;
         }
     }
 }
