@@ -720,12 +720,14 @@ def test_driver_rereads_torn_records(device_moves):
         assert res[0][1][key] == res[1][1][key]
 
 
-def test_total_energy_kernels_of_large_batches(orc):
+@pytest.mark.parametrize("k", [1, 4])
+def test_total_energy_kernels_of_large_batches(k, orc):
     """R = 256 takes the many-replica forms of the total-energy kernels (a wave per pair of
-    molecules for the pair part, a wave per (kx, ky) column for the structure factor): replicas
+    molecules for the pair part; for the structure factor a workgroup per replica with every
+    atom's phases in LDS -- 17 KB at 100 molecules, 126 KB of the 160 KB at 750): replicas
     holding three different configurations against the oracle, terms and S(k)."""
-    a1 = common.nist_arrays(1, "unwrapped")
-    a2 = common.nist_arrays(1, "reference")
+    a1 = common.nist_arrays(k, "unwrapped")
+    a2 = common.nist_arrays(k, "reference")
     rng = np.random.default_rng(3)
     shifted = dict(a1, com=a1["com"].copy(), coords=a1["coords"].copy())
     d = (rng.random(3) - 0.5) * 0.4
