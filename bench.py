@@ -147,7 +147,7 @@ def shape_for(R, args):
 def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, persistent=None):
     """One timed run of the native driver on a fresh batch of R replicas.  Returns the figures of
     this rank; the caller reduces over ranks.  `persistent`: the move server for small batches
-    (None = the --persistent flag; the library's default takes it up to 64 replicas)."""
+    (None = the --persistent flag; the library's default takes it up to 128 replicas)."""
     from metropolismontecarlo_amd import sharding, structs
     from metropolismontecarlo_amd.device import Batch
     box = a["box"]
@@ -284,7 +284,7 @@ def main():
     ap.add_argument("--device-moves", type=int, default=1,
                     help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
     ap.add_argument("--persistent", type=int, default=-1,
-                    help="move server for small batches: -1 = library default (up to 64 replicas), "
+                    help="move server for small batches: -1 = library default (up to 128 replicas), "
                          "0 = a launch per step, 1 = insist")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

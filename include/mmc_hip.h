@@ -244,7 +244,7 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      with n_parts = the server's waves (ceil(molecules / 64) + 1, at most 8 -- 5 for
  *                      a single replica -- or mmc_run_params.n_parts when > 1).  Every device-side wait is bounded (3 s):
  *                      a host that stops talking gets MMC_ERR_HIP from the run, not a hung GPU.
- *                      -1 (default) = use it for up to 64 replicas when it applies, 0 = never,
+ *                      -1 (default) = use it for up to 128 replicas when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
  *   "server_stall_ms"  test hook: the driver sleeps this long before posting the control words of
  *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP) */

@@ -91,7 +91,7 @@ def test_server_chains_with_step_adjustment():
 
 
 def test_server_default_is_automatic_and_uses_fewer_launches():
-    """persistent = -1 (default): device_moves batches of up to 64 replicas take the server; its
+    """persistent = -1 (default): device_moves batches of up to 128 replicas take the server; its
     runs count one `launch` per step and group all the same (a control-word post)."""
     a = common.nist_arrays(1, "unwrapped")
     res = []
