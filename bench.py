@@ -140,8 +140,9 @@ def shape_for(R, args):
     steps = args.steps if args.steps is not None else (3000 if small else 600)
     warmup = args.warmup if args.warmup is not None else (300 if small else 60)
     zero_copy = args.zero_copy_moves if args.zero_copy_moves >= 0 else (1 if small else 0)
+    prewarm = max(0, (120 if not small else 600) - warmup)
     return dict(groups=groups, threads=max(threads, 1), steps=steps, warmup=warmup,
-                zero_copy=zero_copy)
+                zero_copy=zero_copy, prewarm=prewarm)
 
 
 def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, persistent=None):
@@ -168,9 +169,17 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, pers
     tot = b.potential_ewald(as_array=True)      # mmc_totals[R] written straight into numpy
     t_full = time.perf_counter() - t0
     energies = tot["energy"].copy()
-    ev = 0 if args.no_events else max(1, args.event_every)
+    # every Nth launch of a group is bracketed by events; short runs sample more densely
+    ev = 0 if args.no_events else max(1, min(args.event_every, shape["steps"] // 4))
     kw = dict(n_groups=shape["groups"], n_parts=parts, time_kernels=ev, n_threads=shape["threads"],
               n_streams=args.streams, replica0=g0)
+    # Steady state first: the move kernel's launch time keeps falling over the first ~50 launches
+    # of a process (377 -> 355 -> 343 us in three successive 20-step calls), so a short --warmup
+    # would time a device that is still warming up.  These steps are untimed, like the --warmup
+    # ones that follow, and reported as config.prewarm_steps.
+    if shape.get("prewarm", 0) > 0:
+        energies, _ = b.run(shape["prewarm"], TEMPERATURE, DR_MAX, DPHI_MAX,
+                            sharding.run_seed(phase=2), energies, **kw)
     energies, _ = b.run(shape["warmup"], TEMPERATURE, DR_MAX, DPHI_MAX, sharding.run_seed(phase=0),
                         energies, **kw)
     barrier()
@@ -376,6 +385,7 @@ def main():
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
                        "groups_per_gpu": shape["groups"], "host_threads_per_gpu": shape["threads"],
+                       "prewarm_steps": shape["prewarm"],
                        "move_generation": "device" if args.device_moves else "host",
                        "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),

@@ -296,8 +296,9 @@ typedef struct {
     int64_t n_steps;     /* trial moves per replica to run */
     int32_t n_groups;    /* replica groups pipelined on separate streams (>=1) */
     int32_t n_parts;     /* workgroups per replica-move (0 = choose) */
-    int32_t time_kernels;/* N > 0: bracket every Nth launch of a group with HIP events
-                            (stats.kernel_ms over stats.timed_launches); 0: none */
+    int32_t time_kernels;/* N > 0: bracket every Nth launch of a group with HIP events, the
+                            (N/2 + 1)th of each window of N (stats.kernel_ms over
+                            stats.timed_launches); 0: none */
     int32_t n_threads;   /* host threads sharing the groups (0 or 1 = the calling thread only) */
     int32_t n_streams;   /* HIP streams the groups are spread over; 0 = choose (one per group with
                             host proposals, one for all with "device_moves") */
