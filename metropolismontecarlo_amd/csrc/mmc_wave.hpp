@@ -15,6 +15,9 @@
 //   * lane n holds neighbour n's whole 96-byte record in registers (six 16-byte loads straight
 //     from HBM/L2, no LDS staging) and runs the 9 atom pairs x 2 states over it; the LJ term of a
 //     pair with eps > 0.001 reuses the Coulomb term's minimum-image vector and r^2;
+//   * the COM scan runs on 16-bit box fractions of the centres of mass (mmc_kernels.hpp:
+//     com_quant; the wrapped integer difference is the minimum image) and only decides which
+//     records are gathered -- the reference's fp64 comparison on the record decides the rest;
 //   * the COM scan, the neighbour loop and the reciprocal loop each run at >= 90 % lane
 //     utilisation (750 / 768, 117 / 128, 337 / 384);
 //   * workgroups are persistent (grid = a few per CU, each wave loops over units), so the 14 KB
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
 // =================================================================================================
 // k_total_wave -- the pair part of potential(..., "ewald") (Ewald/energy.jl:972-1001) on the same
 // scheme as k_move_eval_wave: a wave per unit, lane per neighbour, the chosen molecule in scalar
-// registers, fp32 prefilter + exact fp64 gate, erfc table.
+// registers, fixed-point prefilter + exact fp64 gate, erfc table.
 //
 // Every molecule pair is visited once (i < j; see mmc_total.hpp for why that equals the
 // reference's "twice, then halve" up to summation order, and how the overlap sentinel is kept).
