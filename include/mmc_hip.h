@@ -75,7 +75,9 @@ int32_t mmc_upload_system(mmc_ctx *ctx, int64_t n_mol, int64_t n_atoms, const do
                           int64_t n_types, const double *eps, const double *sig, double box);
 /* Loop() writes the moved molecule into moa.COM[i] / soa.coords[first:last] before it calls the
  * energy functions (Ewald/main.jl:527,552) and restores them on rejection (:623-624); this is the
- * device-side counterpart of those two assignments.  `atoms`: 3*(last-first+1) doubles. */
+ * device-side counterpart of those two assignments.  `atoms`: 3*(last-first+1) doubles.
+ * The context compares with its host mirror of the coordinates: an unchanged molecule costs nothing,
+ * a changed one travels with the next evaluation instead of a launch of its own. */
 int32_t mmc_set_molecule(mmc_ctx *ctx, int64_t i, const double *com, const double *atoms);
 /* Re-send every centre of mass and atom position (same topology): the whole-array form of the
  * assignments above, for callers that changed more than one molecule on the host.  `com` may be
@@ -100,7 +102,20 @@ int32_t mmc_get_kvectors(mmc_ctx *ctx, int32_t *kxyz /* [NKVECS][3] */, double *
 int32_t mmc_get_sumqexp(mmc_ctx *ctx, double *sum_old, double *sum_new);
 int32_t mmc_set_sumqexp(mmc_ctx *ctx, const double *sum_old, const double *sum_new);
 
-/* LJ_poly_dU(i, moa, soa, vdwTable, r_cut, box)               Ewald/energy.jl:209-290
+/* How the per-molecule calls are served.  Loop() calls LJ_poly_dU(i) and EwaldShort(i) in pairs on
+ * an unchanged system (Ewald/main.jl:491+501, :557+566).  The context evaluates BOTH terms in one
+ * command whichever is asked for first (the cutoff of the other term is assumed to be the one last
+ * used for it, else the same) and answers the second call from that result without touching the
+ * device -- valid as long as molecule, cutoffs and coordinates (a version number of the host
+ * mirror) are unchanged.  For systems of identical 3-site molecules with an EWALD the evaluations
+ * run on a persistent kernel (csrc/mmc_ctxsrv.hpp) that the host talks to through a command block
+ * in pinned memory: no launch, no stream synchronisation per call; every wait is bounded, and the
+ * kernel is stopped before anything else runs on the context (and after ~1 s without a call).
+ * Other systems pay one launch per evaluation.  Results of the two paths agree to ~1e-13
+ * relative (summation order; the server takes erfc(kappa r)/r from the table of the batch
+ * kernels).
+ *
+ * LJ_poly_dU(i, moa, soa, vdwTable, r_cut, box)               Ewald/energy.jl:209-290
  * (and the legacy LJ_poly_dU(i, system::Requirements)          Ewald/energy.jl:126-206)
  * -> (4*pot, 24*vir/3). */
 int32_t mmc_lj_poly_du(mmc_ctx *ctx, int64_t i, double r_cut, double *pot, double *vir);
@@ -133,10 +148,47 @@ int32_t mmc_recip_long(mmc_ctx *ctx, double *energy);
 int32_t mmc_recip_move(mmc_ctx *ctx, const double *r_old, const double *r_new, const double *q,
                        int64_t n, double *d_energy);
 
-/* ewald.sumQExpOld = copy(ewald.sumQExpNew)                   Ewald/main.jl:621 */
+/* ewald.sumQExpOld = copy(ewald.sumQExpNew)                   Ewald/main.jl:621
+ * (on the device the two arrays are names of buffers: a commit or rollback renames, nothing is copied) */
 int32_t mmc_recip_commit(mmc_ctx *ctx);
 /* ewald.sumQExpNew = copy(ewald.sumQExpOld)                   Ewald/main.jl:628 */
 int32_t mmc_recip_rollback(mmc_ctx *ctx);
+
+/* ---- the same calls with the CALLER'S OWN ARRAYS: what a Julia method forwards --------------------
+ * One ccall per reference call, nothing to keep in step by hand.  `com` / `coords` are moa.COM and
+ * soa.coords (legacy: system.rm and qq_r / system.ra) as they are NOW, whole arrays.  Loop() changes
+ * one molecule between calls and may have restored the one of the previous call (main.jl:527,552,
+ * 623-624): the context looks at molecule i and at the molecule of its previous mmc_call_*, compares
+ * them with its mirror, and sends what changed along with the evaluation.  After any other edit of
+ * the arrays call mmc_update_system.
+ *
+ * mmc_call_recip_move takes ewalds.sumQExpOld / sumQExpNew as they are now.  Loop() rebinds them to
+ * copies on every move (main.jl:621,628), so the context finds out which of its device buffers
+ * each array is by CONTENT, against pinned host copies of those buffers (two 5.4 KB comparisons
+ * on the host; arrays it has never seen are uploaded).  When the moved molecule was evaluated by
+ * mmc_call_lj_poly_du / mmc_call_ewald_short while the device still held its old coordinates,
+ * RecipMove was computed in that same command: the call then only checks r_old / r_new / q and the
+ * arrays and copies sumQExpNew out.  sum_new is updated in place like the reference's
+ * (ewalds.jl:805-814); d_energy has the factor applied (:825). */
+int32_t mmc_call_lj_poly_du(mmc_ctx *ctx, int64_t i, const double *com, const double *coords,
+                            double r_cut, double *pot, double *vir);
+int32_t mmc_call_ewald_real(mmc_ctx *ctx, int64_t i, const double *com, const double *coords,
+                            double r_cut, double ovr, double *pot, int32_t *overlap);
+int32_t mmc_call_ewald_short(mmc_ctx *ctx, int64_t i, const double *com, const double *coords,
+                             double qq_rcut, double *e, double *v, int32_t *overlap);
+int32_t mmc_call_recip_move(mmc_ctx *ctx, const double *r_old, const double *r_new,
+                            const double *q, int64_t n, const double *sum_old, double *sum_new,
+                            double *d_energy);
+/* Counters of the context: out[0..7] = commands answered by the persistent kernel, launches of it,
+ * commands that had to be repeated on a fresh one, per-molecule calls answered from the cached
+ * evaluation, RecipMoves answered from the speculative sum, speculative sums that went unused,
+ * evaluations by ordinary launch, 1 if the persistent kernel is running. */
+int32_t mmc_ctx_stats(mmc_ctx *ctx, int64_t out[8]);
+/* Test hook / measurement: average round trip in microseconds of n empty commands through the
+ * running persistent kernel -- the floor under every served call. */
+int32_t mmc_ctx_ping(mmc_ctx *ctx, int64_t n, double *us_avg);
+/* "server": 1 (default) = use the persistent kernel when it applies, 0 = a launch per evaluation */
+int32_t mmc_ctx_set_option(mmc_ctx *ctx, const char *key, int64_t value);
 
 /* EwaldSelf(ewald, qq_q)                                      Ewald/ewalds.jl:829-833 (factor in) */
 int32_t mmc_ewald_self(mmc_ctx *ctx, double *self_energy);

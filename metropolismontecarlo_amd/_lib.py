@@ -110,6 +110,13 @@ SIGNATURES = {
     "mmc_coulomb_real": [_vp, _i64, _d, _dp, _i32p],
     "mmc_recip_long": [_vp, _dp],
     "mmc_recip_move": [_vp, _dp, _dp, _dp, _i64, _dp],
+    "mmc_call_lj_poly_du": [_vp, _i64, _vp, _vp, _d, _dp, _dp],
+    "mmc_call_ewald_real": [_vp, _i64, _vp, _vp, _d, _d, _dp, _i32p],
+    "mmc_call_ewald_short": [_vp, _i64, _vp, _vp, _d, _dp, _dp, _i32p],
+    "mmc_call_recip_move": [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _dp],
+    "mmc_ctx_stats": [_vp, _i64p],
+    "mmc_ctx_ping": [_vp, _i64, _dp],
+    "mmc_ctx_set_option": [_vp, C.c_char_p, _i64],
     "mmc_recip_commit": [_vp],
     "mmc_recip_rollback": [_vp],
     "mmc_ewald_self": [_vp, _dp],

@@ -7,23 +7,25 @@ module with the same methods over `ccall` is metropolismontecarlo_amd/julia/MMCH
 
 Device mirroring.  The reference keeps everything in host arrays that `Loop` mutates between calls
 (moa.COM[i], soa.coords[first:last], ewald.sumQExpOld/New).  A *session* (one mmc_ctx) is attached
-to each `soa`; before a per-molecule call the session re-sends molecule i and the molecule it sent
-last time (which `Loop` may have restored on rejection, main.jl:623-624): that is exactly the set of
-entries `Loop` can have changed.  Total-energy calls re-send all coordinates.  The structure-factor
-arrays live on the device; `RecipMove`/`RecipLong` write the result back into `ewald.sumQExpNew`/
-`sumQExpOld` and, before computing, push the host arrays if the caller rebound them (main.jl:621,628
-rebind them to copies) -- detected by comparing their content with what the device was last
-given (object identity is recycled by the allocator).  `sync_system(moa, soa)` forces a full
-re-send after arbitrary host edits.
+to each `soa`.  A per-molecule call is ONE call into the library (mmc_call_lj_poly_du /
+mmc_call_ewald_short / mmc_call_recip_move, include/mmc_hip.h) with the addresses of the caller's
+arrays as they are now: the library looks at molecule i and at the molecule of the previous call
+(which `Loop` may have restored on rejection, main.jl:623-624) -- exactly the entries `Loop` can
+have changed -- evaluates LJ and real-space Coulomb together, answers the second of
+LJ_poly_ΔU(i) / EwaldShort(i) from that result, and computes RecipMove with the evaluation of the
+moved molecule; which device buffer `ewald.sumQExpOld` / `sumQExpNew` are (Loop rebinds them to
+copies, main.jl:621,628) is found by content on the host.  Total-energy calls re-send all
+coordinates.  `sync_system(moa, soa)` forces a full re-send after arbitrary host edits.
 
 Nothing here computes energies on the host: without the HIP library and a GPU every function
 raises.
 """
+import ctypes as C
 import weakref
 
 import numpy as np
 
-from . import structs
+from . import _lib, structs
 from .device import Context
 from .structs import EWALD, Properties, Requirements, StructArray, Tables
 
@@ -40,6 +42,22 @@ def vector1D(c1, c2, box_size):
     return (c2 - c1) if (c1 - c2) < (c2 - c1 + box_size) else (c2 - c1 + box_size)
 
 
+def _addr(obj, attr, cache, dtype=np.float64):
+    """Address of the array behind obj.attr (a contiguous array of `dtype`; anything else is
+    converted once and put back).  cache: [array object, address] of the last look."""
+    arr = getattr(obj, attr)
+    if arr is cache[0]:
+        return cache[1]
+    if not (isinstance(arr, np.ndarray) and arr.dtype == dtype and arr.flags.c_contiguous
+            and arr.flags.writeable):
+        arr = np.ascontiguousarray(arr, dtype=dtype)
+        if not arr.flags.writeable:
+            arr = arr.copy()
+        setattr(obj, attr, arr)
+    cache[0], cache[1] = arr, arr.ctypes.data
+    return cache[1]
+
+
 class _Session:
     def __init__(self, moa, soa, table, box, device=0):
         self.ctx = Context(device)
@@ -51,55 +69,91 @@ class _Session:
         else:
             eps, sig = table.eps_ij, table.sig_ij
             self.has_table = True
+        self.table = table
         self.table_sig = None if table is None else (eps.tobytes(), sig.tobytes())
         self.ctx.upload_system(moa.COM, moa.firstAtom, moa.lastAtom, soa.coords, soa.atype,
                                soa.charge, eps, sig, box)
         self.box = float(box)
-        self.last_mol = None
         self.ewald_key = None
-        self.s_ids = (None, None)  # host copies of what the device S buffers hold
+        self.ewald_obj = None
         self.moa = weakref.ref(moa)
         self._soa_coords_id = id(soa.coords)
+        # hot path: the library handle, reusable out-parameters, cached array addresses
+        self._L = _lib.lib()
+        self._h = self.ctx._h
+        self._o1, self._o2, self._oi = C.c_double(), C.c_double(), C.c_int32()
+        self._r1, self._r2, self._ri = C.byref(self._o1), C.byref(self._o2), C.byref(self._oi)
+        self._com, self._coords = [None, 0], [None, 0]
+        self._so, self._sn = [None, 0], [None, 0]
 
-    def sync_molecule(self, moa, soa, i):
-        for m in {i, self.last_mol} - {None}:
-            f, l = int(moa.firstAtom[m - 1]), int(moa.lastAtom[m - 1])
-            self.ctx.set_molecule(m, moa.COM[m - 1], soa.coords[f - 1:l])
-        self.last_mol = i
+    # ---- one library call per reference call (include/mmc_hip.h, mmc_call_*) ----
+    def lj(self, i, moa, soa, r_cut):
+        st = self._L.mmc_call_lj_poly_du(self._h, i, _addr(moa, "COM", self._com),
+                                         _addr(soa, "coords", self._coords), r_cut, self._r1, self._r2)
+        if st:
+            _lib.check(st)
+        return self._o1.value, self._o2.value
+
+    def ewald_short(self, i, moa, soa, qq_rcut):
+        st = self._L.mmc_call_ewald_short(self._h, i, _addr(moa, "COM", self._com),
+                                          _addr(soa, "coords", self._coords), qq_rcut, self._r1,
+                                          self._r2, self._ri)
+        if st:
+            _lib.check(st)
+        return self._o1.value, self._o2.value, bool(self._oi.value)
+
+    def ewald_real(self, i, moa, soa, r_cut, ovr):
+        st = self._L.mmc_call_ewald_real(self._h, i, _addr(moa, "COM", self._com),
+                                         _addr(soa, "coords", self._coords), r_cut, ovr, self._r1,
+                                         self._ri)
+        if st:
+            _lib.check(st)
+        return self._o1.value, bool(self._oi.value)
+
+    def recip_move(self, ewald, r_old, r_new, qq_q):
+        r_old = np.ascontiguousarray(r_old, dtype=np.float64)
+        r_new = np.ascontiguousarray(r_new, dtype=np.float64)
+        qq_q = np.ascontiguousarray(qq_q, dtype=np.float64)
+        n = self.ctx.nkvecs
+        if len(ewald.sumQExpOld) != n or len(ewald.sumQExpNew) != n:
+            raise ValueError("ewald.sumQExpOld/New do not have NKVECS entries")
+        st = self._L.mmc_call_recip_move(self._h, r_old.ctypes.data, r_new.ctypes.data,
+                                         qq_q.ctypes.data, len(qq_q),
+                                         _addr(ewald, "sumQExpOld", self._so, np.complex128),
+                                         _addr(ewald, "sumQExpNew", self._sn, np.complex128),
+                                         self._r1)
+        if st:
+            _lib.check(st)
+        return self._o1.value
 
     def sync_all(self, moa, soa):
         self.ctx.update_system(moa.COM, soa.coords)
-        self.last_mol = None
 
     def bind_ewald(self, ewald, box):
+        if ewald is self.ewald_obj and self.ewald_key == (ewald.kappa, ewald.nk, ewald.k_sq_max,
+                                                          ewald.factor, box):
+            return
         key = (ewald.kappa, ewald.nk, ewald.k_sq_max, ewald.factor, float(box))
         if self.ewald_key != key:
             n = self.ctx.prepare_ewald(ewald.kappa, ewald.nk, ewald.k_sq_max, box, ewald.factor)
             self.ewald_key = key
-            self.s_ids = (None, None)
             if ewald.NKVECS != n:  # a dummy EWALD as at main.jl:290-301
                 ewald.NKVECS = n
+        self.ewald_obj = ewald
         ewald._session = self
 
     def push_s(self, ewald):
-        """Send sumQExpOld/New when the host arrays differ from what the device holds (Loop
-        rebinds them to copies, main.jl:621,628).  Compared by CONTENT -- 337 complex numbers --
-        because object identity can be recycled by the allocator."""
+        """Send sumQExpOld/New (arrays the device has not produced itself)."""
         so = np.asarray(ewald.sumQExpOld, dtype=np.complex128)
         sn = np.asarray(ewald.sumQExpNew, dtype=np.complex128)
-        if len(so) != self.ctx.nkvecs or len(sn) != self.ctx.nkvecs:
-            return
-        m = self.s_ids
-        if m[0] is None or not (np.array_equal(so, m[0]) and np.array_equal(sn, m[1])):
+        if len(so) == self.ctx.nkvecs and len(sn) == self.ctx.nkvecs:
             self.ctx.set_sumqexp(so, sn)
-            self.s_ids = (so.copy(), sn.copy())
 
     def pull_s(self, ewald, old=False):
         so, sn = self.ctx.get_sumqexp()
         if old:
             ewald.sumQExpOld = so
         ewald.sumQExpNew = sn
-        self.s_ids = (so.copy(), sn.copy())
 
 
 _sessions = {}
@@ -108,10 +162,25 @@ _sessions = {}
 def _drop(key):
     s = _sessions.pop(key, None)
     if s is not None:
+        if _last[4] is s:
+            _last[:] = [None, None, None, None, None]
         s.ctx.close()
 
 
+_last = [None, None, None, None, None]  # soa, moa, table, box, session of the last look-up
+
+
 def _session(moa, soa, table, box):
+    if soa is _last[0] and moa is _last[1] and box == _last[3] and (table is None or table is _last[2]):
+        s = _last[4]
+        if s.ctx._h is not None and len(soa.coords) == s.ctx.n_atoms:
+            return s
+    s = _session_slow(moa, soa, table, box)
+    _last[:] = [soa, moa, s.table, float(box), s]
+    return s
+
+
+def _session_slow(moa, soa, table, box):
     key = id(soa)
     s = _sessions.get(key)
     stale = s is not None and (s.box != float(box) or s.ctx.n_atoms != len(soa.coords)
@@ -180,8 +249,7 @@ def LJ_poly_ΔU(i, *args):
         s.sync_all(moa, soa)
     else:
         moa, soa, vdwTable, r_cut, box = args
-        s = _session(moa, soa, vdwTable, box)
-        s.sync_molecule(moa, soa, i)
+        return _session(moa, soa, vdwTable, box).lj(i, moa, soa, r_cut)
     return s.ctx.lj_poly_du(i, r_cut)
 
 
@@ -193,8 +261,7 @@ def EwaldReal(*args):
         chosenOne, moa, soa, ewald, r_cut, box = args
         s = _session(moa, soa, None, box)
         s.bind_ewald(ewald, box)
-        s.sync_molecule(moa, soa, chosenOne)
-        return s.ctx.ewald_real(chosenOne, r_cut, 0.5)
+        return s.ewald_real(chosenOne, moa, soa, r_cut, 0.5)
     qq_r, qq_q, kappa, box, thisMol_thisAtom, chosenOne, system = args
     moa, soa = _as_moa_soa(system)
     soa.coords[...] = np.asarray(qq_r, dtype=np.float64).reshape(-1, 3)
@@ -211,8 +278,7 @@ def EwaldShort(i, moa, soa, sim_props, ewald, box):
     """Ewald/ewalds.jl:892-910 -> (e, e/3, overlap), factor applied."""
     s = _session(moa, soa, None, box)
     s.bind_ewald(ewald, box)
-    s.sync_molecule(moa, soa, i)
-    return s.ctx.ewald_short(i, sim_props.qq_rcut)
+    return s.ewald_short(i, moa, soa, sim_props.qq_rcut)
 
 
 def CoulombReal(qq_r, qq_q, box, chosenOne, system):
@@ -266,7 +332,6 @@ def RecipLong(*args):
         moa = s.moa()
         # all atoms matter here: re-send the coordinates the caller passed
         s.ctx.update_system(moa.COM, np.asarray(r, dtype=np.float64).reshape(-1, 3))
-        s.last_mol = None
     s.bind_ewald(ewald, box)
     energy = s.ctx.recip_long()
     s.pull_s(ewald, old=True)
@@ -286,27 +351,20 @@ def RecipMove(box, ewalds, r_old, r_new, qq_q):
         if ewalds.k_sq_max != 27:
             raise AssertionError("k_sq_max == 27 (ewalds.jl:742)")
         s.bind_ewald(ewalds, box)
-    s.push_s(ewalds)
-    de = s.ctx.recip_move(r_old, r_new, qq_q)
-    s.pull_s(ewalds)
-    return de, ewalds
+    return s.recip_move(ewalds, r_old, r_new, qq_q), ewalds
 
 
 def RecipCommit(ewald):
     """`ewald.sumQExpOld = [item for item in ewald.sumQExpNew]` (Ewald/main.jl:621) done on the
     device; keeps the host arrays in step."""
-    s = ewald._session
-    s.ctx.recip_commit()
+    ewald._session.ctx.recip_commit()
     ewald.sumQExpOld = ewald.sumQExpNew.copy()
-    s.s_ids = (ewald.sumQExpOld.copy(), ewald.sumQExpNew.copy())
 
 
 def RecipRollback(ewald):
     """`ewald.sumQExpNew = [item for item in ewald.sumQExpOld]` (Ewald/main.jl:628)."""
-    s = ewald._session
-    s.ctx.recip_rollback()
+    ewald._session.ctx.recip_rollback()
     ewald.sumQExpNew = ewald.sumQExpOld.copy()
-    s.s_ids = (ewald.sumQExpOld.copy(), ewald.sumQExpNew.copy())
 
 
 def EwaldSelf(ewald, qq_q):

@@ -268,9 +268,10 @@ struct RecipMoveArgs {
     double r_old[9], r_new[9], q[3];
 };
 
-// ewalds.jl:718-826.  S(0) = sumQExpOld, S(1) = sumQExpNew; S(1) += dS in place (:805-814).
+// ewalds.jl:718-826.  S(a_old) = sumQExpOld, S(a_new) = sumQExpNew; S(a_dst) = S(a_new) + dS
+// (a_dst == a_new: in place, :805-814), energy against S(a_old) (:817-821).
 __global__ __launch_bounds__(MMC_BLOCK) void k_recip_move(BatchView bv, RecipMoveArgs a,
-                                                          double *out)
+                                                          double *out, int a_old, int a_new, int a_dst)
 {
     __shared__ cplx tab[2][3][3][MMC_NKTAB];
     __shared__ double red[MMC_WAVES];
@@ -280,12 +281,12 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_recip_move(BatchView bv, RecipMov
         phase_row(x, bv.box, tab[st][l][d]);
     }
     __syncthreads();
-    const double *So = s_buf(bv, 0, 0);
-    double *Sn = s_buf(bv, 0, 1);
+    const double *So = s_buf(bv, 0, a_old), *Si = s_buf(bv, 0, a_new);
+    double *Sn = s_buf(bv, 0, a_dst);
     double v[1] = { 0.0 }, tot[1];
     for (int k = threadIdx.x; k < bv.nkvecs; k += MMC_BLOCK) {
         const int kx = bv.kxyz[3 * k], ky = bv.kxyz[3 * k + 1], kz = bv.kxyz[3 * k + 2];
-        double nr = Sn[2 * k], ni = Sn[2 * k + 1];
+        double nr = Si[2 * k], ni = Si[2 * k + 1];
 #pragma unroll
         for (int l = 0; l < 3; l++) {
             const cplx tn = c_mul(c_mul(tab[1][l][0][5 + kx], tab[1][l][1][5 + ky]),
