@@ -239,6 +239,22 @@ class Context:
     def accept_move(self):
         check(self._L.mmc_accept_move(self._h))
 
+    def stats(self):
+        """mmc_ctx_stats: counters of the context's engine (persistent kernel, cache, speculation)."""
+        st = (C.c_int64 * 8)()
+        check(self._L.mmc_ctx_stats(self._h, st))
+        return dict(zip(("cmds", "launches", "retries", "cache_hits", "spec_hits", "spec_miss",
+                         "launch_evals", "alive"), list(st)))
+
+    def set_option(self, key, value):
+        check(self._L.mmc_ctx_set_option(self._h, key.encode(), int(value)))
+
+    def ping(self, n=1000):
+        """Average round trip (us) of n empty commands through the running persistent kernel."""
+        us = C.c_double()
+        check(self._L.mmc_ctx_ping(self._h, int(n), C.byref(us)))
+        return us.value
+
     def reject_move(self):
         check(self._L.mmc_reject_move(self._h))
 

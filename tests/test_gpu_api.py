@@ -149,3 +149,152 @@ def test_reference_asserts_surface_as_assertion_errors():
                                       structs.factor), box)
     with pytest.raises(AssertionError):
         RecipMove(box, ew4, np.zeros((3, 3)), np.zeros((3, 3)), np.zeros(3))     # nk == 5, :743
+
+
+# ---- the engine behind the call surface: cached evaluation, stale molecules, named S buffers --------
+def _ctx_stats(ewald):
+    import ctypes
+    s = ewald._session
+    st = (ctypes.c_int64 * 8)()
+    assert s._L.mmc_ctx_stats(s._h, st) == 0
+    return dict(zip(("cmds", "launches", "retries", "cache_hits", "spec_hits", "spec_miss",
+                     "launch_evals", "alive"), list(st)))
+
+
+def _oracle_state(a, moa, soa, orc):
+    s = common.oracle_system(dict(a, com=moa.COM, coords=soa.coords))
+    return s
+
+
+def test_cache_invalidates_when_loop_restores_a_rejected_molecule(orc):
+    """Loop() restores COM/atoms of a rejected molecule (main.jl:623-624): the evaluation cached
+    for the moved state must not answer the next call, and the second of LJ_poly_dU(i) /
+    EwaldShort(i) on an unchanged system must not reach the device."""
+    a = common.nist_arrays(4, "unwrapped")
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+    ewo = orc.Ewald(5.6 / box, 5, 27, box)
+    rng = np.random.default_rng(3)
+    for step, i in enumerate((11, 12, 12, 400, 11)):
+        f, l = moa.firstAtom[i - 1], moa.lastAtom[i - 1]
+        s0 = _oracle_state(a, moa, soa, orc)
+        st0 = _ctx_stats(ewald)
+        e_old, v_old = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+        q_old, w_old, _ = EwaldShort(i, moa, soa, totProps, ewald, box)
+        st1 = _ctx_stats(ewald)
+        assert st1["cmds"] + st1["launch_evals"] - st0["cmds"] - st0["launch_evals"] <= 1
+        # EwaldShort came from the cache (and LJ_poly_dU too when nothing changed since molecule
+        # i was last evaluated: step 2 repeats the molecule of an accepted step 1)
+        assert st1["cache_hits"] == st0["cache_hits"] + (2 if step == 2 else 1)
+        eo, vo = orc.lj_poly_du(i, s0, RCUT)
+        qo, wo, _ = orc.ewald_short(i, s0, ewo, RCUT)
+        assert rel(e_old, eo) < TOL and rel(q_old, qo) < TOL
+        rm_old, ra_old = moa.COM[i - 1].copy(), soa.coords[f - 1:l].copy()
+        d = (rng.random(3) - 0.5) * 0.3
+        moa.COM[i - 1] += d
+        soa.coords[f - 1:l] += d
+        s1 = _oracle_state(a, moa, soa, orc)
+        e_new, _ = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+        q_new, _, _ = EwaldShort(i, moa, soa, totProps, ewald, box)
+        en, _ = orc.lj_poly_du(i, s1, RCUT)
+        qn, _, _ = orc.ewald_short(i, s1, ewo, RCUT)
+        assert rel(e_new, en) < TOL and rel(q_new, qn) < TOL and e_new != e_old
+        if step % 2 == 0:   # rejected: Loop restores the molecule (main.jl:623-624)
+            moa.COM[i - 1] = rm_old
+            soa.coords[f - 1:l] = ra_old
+            e_again, _ = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+            q_again, _, _ = EwaldShort(i, moa, soa, totProps, ewald, box)
+            assert rel(e_again, eo) < TOL and rel(q_again, qo) < TOL
+            assert e_again != e_new                            # not the cached moved state
+    assert _ctx_stats(ewald)["retries"] == 0
+
+
+def test_recip_move_array_roles_follow_the_callers_arrays(orc):
+    """RecipMove twice without a commit (sumQExpNew accumulates in place, ewalds.jl:805-814), a
+    commit, a rollback, and arrays the context has never seen -- each against the oracle doing
+    the same to its own EWALD."""
+    a = common.nist_arrays(1, "reference")
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+    s = common.oracle_system(a)
+    ewo = orc.Ewald(5.6 / box, 5, 27, box)
+    orc.recip_long(ewo, s.coords, s.charge, box)
+    q = a["charge"][:3]
+    rng = np.random.default_rng(5)
+
+    def both(r_old, r_new):
+        de, _ = RecipMove(box, ewald, r_old, r_new, q)
+        deo = orc.recip_move(box, ewo, r_old, r_new, q)
+        assert abs(de - deo) < TOL * 1e5
+        scale = np.abs(ewo.sumQExpNew).max()
+        assert np.abs(ewald.sumQExpNew - ewo.sumQExpNew).max() < 1e-11 * scale
+        assert np.abs(ewald.sumQExpOld - ewo.sumQExpOld).max() < 1e-11 * scale
+
+    r0 = a["coords"][:3].copy()
+    r1 = r0 + (rng.random(3) - 0.5)
+    r2 = r1 + (rng.random(3) - 0.5)
+    both(r0, r1)
+    both(r1, r2)                                  # unsettled: in place on sumQExpNew
+    ewald.sumQExpOld = ewald.sumQExpNew.copy()    # main.jl:621
+    ewo.sumQExpOld = ewo.sumQExpNew.copy()
+    both(r2, r0)
+    ewald.sumQExpNew = ewald.sumQExpOld.copy()    # main.jl:628
+    ewo.sumQExpNew = ewo.sumQExpOld.copy()
+    both(r2, r1)
+    # arrays from somewhere else
+    ewald.sumQExpOld = ewald.sumQExpOld * 0.5 + 0.25j
+    ewald.sumQExpNew = ewald.sumQExpNew * 2.0 - 0.5
+    ewo.sumQExpOld = ewald.sumQExpOld.copy()
+    ewo.sumQExpNew = ewald.sumQExpNew.copy()
+    both(r1, r0)
+    both(r0, r2)
+
+
+def test_many_stale_molecules_and_an_idle_server(orc):
+    """More molecules changed between two calls than one command carries, a pause longer than
+    the host's re-launch threshold, and one longer than the server's own bounded wait."""
+    import time
+    a = common.nist_arrays(2, "unwrapped")
+    with common.device_context(a) as ctx:
+        s = common.oracle_system(a)
+        ewo = orc.Ewald(5.6 / a["box"], 5, 27, a["box"])
+        rng = np.random.default_rng(9)
+        for pause in (0.0, 0.4, 1.3):
+            for m in rng.choice(np.arange(1, 201), size=7, replace=False):
+                d = (rng.random(3) - 0.5) * 0.2
+                s.com[m - 1] += d
+                s.coords[3 * (m - 1):3 * m] += d
+                ctx.set_molecule(int(m), s.com[m - 1], s.coords[3 * (m - 1):3 * m])
+            time.sleep(pause)
+            for i in (3, 77, 200):
+                p, v = ctx.lj_poly_du(i, RCUT)
+                e, w, ov = ctx.ewald_short(i, RCUT)
+                po, vo = orc.lj_poly_du(i, s, RCUT)
+                eo, wo, ovo = orc.ewald_short(i, s, ewo, RCUT)
+                assert rel(p, po) < TOL and rel(v, vo, abs(po)) < TOL and rel(e, eo) < TOL and ov == ovo
+        com, coords = ctx.download_system()
+        assert np.array_equal(com, s.com) and np.array_equal(coords, s.coords)
+        st = ctx.stats()
+        assert st["launches"] >= 3 and st["cmds"] > 0
+
+
+def test_server_and_launch_paths_agree(orc):
+    a = common.nist_arrays(3, "unwrapped")
+    res = []
+    for server in (1, 0):
+        with common.device_context(a) as ctx:
+            ctx.set_option("server", server)
+            ctx.recip_long()
+            out = []
+            for i in (1, 150, 300):
+                out.append(ctx.lj_poly_du(i, RCUT) + ctx.ewald_short(i, RCUT)[:2])
+            mv = common.golden(3, "unwrapped")["moves"][0]
+            d, ov = ctx.trial_move(mv["mol"], mv["com_new"], mv["atoms_new"], RCUT, RCUT)
+            ctx.accept_move() if not ov else ctx.reject_move()
+            out.append(tuple(d))
+            out.append(ctx.lj_poly_du(mv["mol"], RCUT))
+            st = ctx.stats()
+            assert (st["cmds"] > 0) == bool(server) and (st["launch_evals"] > 0) != bool(server)
+            res.append(np.concatenate([np.ravel(x) for x in out]))
+    scale = np.maximum(np.abs(res[0]), 1.0)
+    assert (np.abs(res[0] - res[1]) / scale).max() < 1e-11
