@@ -5,7 +5,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]/[2]): SPC/E water, 750 molecules (NIST sample configuration 4 ==
-Ewald/coord750.txt, committed as tests/golden/spce_nist.npz), NVT at 298.15 K, full Ewald
+Ewald/coord750.txt, shipped as metropolismontecarlo_amd/data/spce_nist.npz), NVT at 298.15 K, full Ewald
 (kappa = 5.6/L, 337 k-vectors), fp64, r_cut = 10 A.  R independent replicas per GPU (one Markov
 chain each; chain r of rank k draws from the stream (seed, k*R + r)); replicas shard across ranks
 with no data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of
@@ -33,6 +33,11 @@ One JSON line on stdout (rank 0).  Extra objects:
   full_energy_eval  M2: ns per potential(..., "ewald"), batched over the replicas and as the
                  latency of ONE system (750 and 10 000 molecules), each with its fraction of the
                  fp64 vector peak on the survey's flop count.
+  call_surface   the reference's OWN call surface on one chain: microseconds per LJ_poly_dU /
+                 EwaldShort / RecipMove call and per Loop() body (Ewald/main.jl:487-644) written with
+                 those calls through metropolismontecarlo_amd/api.py (one library call each; what
+                 MMCHip.jl's ccalls cost plus Python), per move through mmc_trial_move, and the same
+                 with a kernel launch per evaluation instead of the context's persistent kernel.
   cpu_baseline   the CPU oracle (a single-threaded C port of the reference's Julia code path; the
                  Julia reference itself cannot run here) timed on this host on the same workload.
 """
@@ -46,7 +51,6 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 TEMPERATURE = 298.15      # Ewald/main.jl:62
 DR_MAX = 0.316555789      # Ewald/main.jl:118
@@ -101,9 +105,9 @@ def cpu_baseline(a, budget_s, n_threads=1):
     calls for successive molecules with small rigid translations, in a C loop
     (orc_bench_trial_moves; n_threads independent chains, one per thread) for `budget_s` seconds.
     Returns (moves/s, moves, seconds, seconds of one full energy evaluation on one thread)."""
-    import common
     from oracle import oracle as orc
-    s = common.oracle_system(a)
+    s = orc.System(a["com"], a["first_atom"], a["last_atom"], a["coords"], a["atype"], a["charge"],
+                   a["eps"], a["sig"], a["box"])
     ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
     orc.recip_long(ew, s.coords, s.charge, s.box)
     n, dt = orc.bench_trial_moves(s, ew, RCUT, RCUT, DR_MAX, SEED, n_threads, budget_s)
@@ -272,6 +276,130 @@ def single_system_latency(a, local_rank):
     return out
 
 
+def call_surface(a, n_moves=2000, n_warm=300):
+    """One Markov chain driven through the reference's own calls: the body of Loop()
+    (Ewald/main.jl:487-644) -- LJ_poly_dU, EwaldShort, move, LJ_poly_dU, EwaldShort, RecipMove,
+    Metropolis, commit or restore -- with the reference's statements and host-array mutations,
+    through api.py.  Times every call class with perf_counter around the call."""
+    from metropolismontecarlo_amd import api, structs
+    from metropolismontecarlo_amd import io as mio
+    from metropolismontecarlo_amd.device import Context
+    from metropolismontecarlo_amd.structs import EWALD, Properties, Properties2, Tables
+    box = a["box"]
+    n_mol = a["com"].shape[0]
+
+    def run(server):
+        os.environ["MMC_CTX_SERVER"] = "1" if server else "0"
+        moa = structs.make_moa(a["com"].copy(), a["first_atom"], a["last_atom"])
+        soa = structs.make_soa(a["coords"].copy(), a["atype"], a["charge"])
+        vdwTable = Tables([mio.SPCE_EPS_O, 0.0], [mio.SPCE_SIGMA_O, 0.0])
+        ewald = EWALD(5.6 / box, 5, 27, 1, [[1, 1, 1]] * 3, [0.0, 0.0], np.zeros(2, complex),
+                      np.zeros(2, complex), structs.factor)                   # main.jl:290-301
+        ewald = api.PrepareEwaldVariables(ewald, box)                          # main.jl:303
+        totProps = Properties2(TEMPERATURE, 0.0331, 0.0, DR_MAX, DPHI_MAX, 0.3, 0, 0, [], RCUT,
+                               RCUT, box)
+        total = api.potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+        running = total.energy
+        rng = np.random.default_rng(SEED)
+        t_call = np.zeros(5)
+        t_body = 0.0
+        n_acc = 0
+        pc = time.perf_counter
+        for s_ in range(n_warm + n_moves):
+            if s_ == n_warm:
+                t_call[:] = 0.0
+                t_body = 0.0
+                n_acc = 0
+                st0 = ewald._session.ctx.stats()
+            i = s_ % n_mol + 1                                                 # main.jl:490
+            f, l = int(moa.firstAtom[i - 1]), int(moa.lastAtom[i - 1])
+            t0 = pc()
+            e0, v0 = api.LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)          # :491
+            t1 = pc()
+            q0, w0, o1 = api.EwaldShort(i, moa, soa, totProps, ewald, box)     # :501
+            t2 = pc()
+            rm_old = moa.COM[i - 1].copy()                                     # :514
+            ra_old = soa.coords[f - 1:l].copy()                                # :515
+            d = (rng.random(3) - 0.5) * DR_MAX                                 # :523 (translations)
+            moa.COM[i - 1] += d
+            soa.coords[f - 1:l] += d                                           # :552
+            ra_new = soa.coords[f - 1:l].copy()
+            t3 = pc()
+            e1, v1 = api.LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)          # :557
+            t4 = pc()
+            q1, w1, o2 = api.EwaldShort(i, moa, soa, totProps, ewald, box)     # :566
+            t5 = pc()
+            dr = 0.0
+            if not (o1 or o2):
+                dr, ewald = api.RecipMove(box, ewald, ra_old, ra_new, soa.charge[f - 1:l])  # :581
+            t6 = pc()
+            delta = (e1 + q1) - (e0 + q0) + dr                                 # :593
+            x = delta / TEMPERATURE
+            if (x < 0 or np.exp(-x) > rng.random()) and not (o1 or o2):        # :598
+                running += delta
+                ewald.sumQExpOld = ewald.sumQExpNew.copy()                     # :621
+                n_acc += 1
+            else:
+                moa.COM[i - 1] = rm_old                                        # :623
+                soa.coords[f - 1:l] = ra_old                                   # :624
+                ewald.sumQExpNew = ewald.sumQExpOld.copy()                     # :628
+            t7 = pc()
+            t_call += (t1 - t0, t2 - t1, t4 - t3, t5 - t4, t6 - t5)
+            t_body += t7 - t0
+        st1 = ewald._session.ctx.stats()
+        ping = ewald._session.ctx.ping(2000) if st1["alive"] else None
+        total2 = api.potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+        drift = abs(running - total2.energy) / abs(total2.energy)
+        api.release_sessions()
+        us = 1e6 * t_call / n_moves
+        return {"us_per_call": {"LJ_poly_dU_old": us[0], "EwaldShort_old": us[1],
+                                "LJ_poly_dU_new": us[2], "EwaldShort_new": us[3],
+                                "RecipMove": us[4]},
+                "us_five_calls": float(us.sum()), "us_loop_body": 1e6 * t_body / n_moves,
+                "acceptance": n_acc / n_moves, "energy_drift_rel": drift,
+                "per_move": {k: (st1[k] - st0[k]) / n_moves
+                             for k in ("cmds", "cache_hits", "spec_hits", "spec_miss",
+                                       "launch_evals")},
+                "server_round_trip_us": ping}
+
+    out = {"workload": "ONE chain, SPC/E 750 molecules: the body of Loop() (Ewald/main.jl:487-644) "
+                       "written with the reference's calls through api.py, one library call each",
+           "moves_timed": n_moves}
+    out.update(run(True))
+    launch = run(False)
+    out["launch_per_evaluation"] = {k: launch[k] for k in ("us_per_call", "us_five_calls",
+                                                           "us_loop_body", "energy_drift_rel")}
+    # the fused form of the same move: mmc_trial_move + mmc_accept_move / mmc_reject_move
+    os.environ["MMC_CTX_SERVER"] = "1"
+    from metropolismontecarlo_amd import structs as st_
+    with Context() as ctx:
+        ctx.upload_system(a["com"], a["first_atom"], a["last_atom"], a["coords"], a["atype"],
+                          a["charge"], a["eps"], a["sig"], box)
+        ctx.prepare_ewald(5.6 / box, 5, 27, box, st_.factor)
+        ctx.potential_ewald(RCUT, RCUT)
+        com, coords = a["com"].copy(), a["coords"].copy()
+        rng = np.random.default_rng(SEED)
+        t_tm = 0.0
+        for s_ in range(n_warm + n_moves):
+            if s_ == n_warm:
+                t_tm = 0.0
+            i = s_ % n_mol + 1
+            d = (rng.random(3) - 0.5) * DR_MAX
+            cn, an = com[i - 1] + d, coords[3 * i - 3:3 * i] + d
+            t0 = time.perf_counter()
+            dd, ov = ctx.trial_move(i, cn, an, RCUT, RCUT)
+            x = (dd[0] + dd[1] + dd[2]) / TEMPERATURE
+            if (x < 0 or np.exp(-x) > rng.random()) and not ov:
+                ctx.accept_move()
+                com[i - 1], coords[3 * i - 3:3 * i] = cn, an
+            else:
+                ctx.reject_move()
+            t_tm += time.perf_counter() - t0
+        out["us_per_move_trial_move"] = 1e6 * t_tm / n_moves
+    os.environ.pop("MMC_CTX_SERVER", None)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -336,10 +464,10 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    import common
+    from metropolismontecarlo_amd import io as mio
     from metropolismontecarlo_amd import sharding
 
-    a = common.nist_arrays(4, "unwrapped")
+    a = mio.load_nist_fixture(4, "unwrapped")
     n_mol, box = a["com"].shape[0], a["box"]
     R = args.replicas
 
@@ -451,6 +579,7 @@ def main():
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry
             out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
+            out["call_surface"] = call_surface(a)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {
@@ -458,7 +587,10 @@ def main():
                 "sample": f"{n} trial moves (2x LJ_poly_dU + 2x EwaldShort + RecipMove) of the "
                           f"same 750-molecule system in {dt:.1f} s, C oracle (C loop), 1 thread",
                 "ns_per_full_energy_eval": 1e9 * tf,
+                "us_per_move": 1e6 / mps,
             }
+            if "call_surface" in out:
+                out["call_surface"]["cpu_port_us_per_move"] = 1e6 / mps
             nt = min(len(os.sched_getaffinity(0)), 64)
             if nt > 1 and args.cpu_seconds >= 2:
                 mps_all, n_all, dt_all, _ = cpu_baseline(a, args.cpu_seconds / 2, nt)

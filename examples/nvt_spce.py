@@ -17,10 +17,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import common  # noqa: E402  (fixture loader: tests/golden/spce_nist.npz)
-from metropolismontecarlo_amd import observables, structs  # noqa: E402
+from metropolismontecarlo_amd import io as mio, observables, structs  # noqa: E402
 from metropolismontecarlo_amd.device import Batch, block_line  # noqa: E402
 
 
@@ -32,7 +30,7 @@ def main():
     ap.add_argument("--temperature", type=float, default=298.15)
     args = ap.parse_args()
 
-    a = common.nist_arrays(4, "unwrapped")
+    a = mio.load_nist_fixture(4, "unwrapped")
     n_mol, box, r_cut = a["com"].shape[0], a["box"], 10.0
     b = Batch(args.replicas, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], box,
               5.6 / box, structs.factor, r_cut, r_cut)

@@ -187,7 +187,8 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
             w = __longlong_as_double((long long)cw[CS_PHYS(CS_W_MV + lane)]);
         const bool do_pairs = (part < np) && (flags & CS_EVAL);
         const bool do_recip = (part == np) && (flags & CS_RECIP);
-        const int pend = -1;
+        const int pend = -1, scur = s_base & 1; // (scur: unused, the buffers are named by macros)
+        (void)scur;
         double *const s_mirror = sa.s_mirror + (int64_t)s_dst * bv.nk_stride * 2;
 #define WV_CQ_BASE cq_base
 #define WV_PART_DST part_dst

@@ -35,6 +35,23 @@ def read_nist_text(path):
     return box, np.array(xyz, dtype=np.float64), np.array(is_o, dtype=bool)
 
 
+_NIST_NPZ = None
+
+
+def load_nist_fixture(k, com="reference"):
+    """NIST SPC/E sample configuration k = 1..4 (100, 200, 300 molecules in a 20 A box, 750 in
+    30 A; configuration 4 is Ewald/coord750.txt) as nist_system() arrays.  The coordinates are
+    public NIST data the reference redistributes; they ship with the package as
+    data/spce_nist.npz (written by tests/golden/make_fixtures.py) because BASELINE's workload and
+    the examples need them where /root/reference does not exist."""
+    global _NIST_NPZ
+    if _NIST_NPZ is None:
+        _NIST_NPZ = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data",
+                                         "spce_nist.npz"))
+    return nist_system(float(_NIST_NPZ[f"box_{k}"]), _NIST_NPZ[f"xyz_{k}"],
+                       _NIST_NPZ[f"is_oxygen_{k}"], com)
+
+
 def nist_system(box, xyz, is_oxygen, com="reference"):
     """Arrays of the SPC/E system as the reference's "nist" branch builds them.
 

@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import common  # noqa: E402
+import common  # noqa: F401
+from metropolismontecarlo_amd import io as mio  # noqa: E402
 from metropolismontecarlo_amd import structs  # noqa: E402
 from metropolismontecarlo_amd.device import Batch  # noqa: E402
 
@@ -45,7 +46,7 @@ def main():
     ap.add_argument("--equil", type=int, default=40)
     ap.add_argument("--prod", type=int, default=40)
     args = ap.parse_args()
-    a = common.nist_arrays(4, "unwrapped")
+    a = mio.load_nist_fixture(4, "unwrapped")
     res = {}
     for name, mode in (("host", 0), ("device", 1)):
         res[name] = run(mode, a, args.replicas, args.equil, args.prod, 4242)

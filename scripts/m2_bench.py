@@ -5,11 +5,12 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import common
+import common  # noqa: F401
+from metropolismontecarlo_amd import io as mio
 from metropolismontecarlo_amd import structs, io as mio
 from metropolismontecarlo_amd.device import Batch, Context
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-a = common.nist_arrays(4, "unwrapped")
+a = mio.load_nist_fixture(4, "unwrapped")
 b = Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
           5.6 / a["box"], structs.factor, 10.0, 10.0)
 b.potential_ewald(as_array=True)

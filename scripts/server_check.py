@@ -4,11 +4,12 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import common
+import common  # noqa: F401
+from metropolismontecarlo_amd import io as mio
 from metropolismontecarlo_amd import structs
 from metropolismontecarlo_amd.device import Batch
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-a = common.nist_arrays(k, "unwrapped")
+a = mio.load_nist_fixture(k, "unwrapped")
 n_mol = a["com"].shape[0]
 P = int(os.environ.get('SRV_P', min((n_mol + 63) // 64, 7) + 1))
 big = int(sys.argv[2]) if len(sys.argv) > 2 else 0

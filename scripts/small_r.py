@@ -5,10 +5,11 @@ import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import common
+import common  # noqa: F401
+from metropolismontecarlo_amd import io as mio
 from metropolismontecarlo_amd import structs
 from metropolismontecarlo_amd.device import Batch
-a = common.nist_arrays(4, "unwrapped")
+a = mio.load_nist_fixture(4, "unwrapped")
 for R in (1, 32):
     for kernel in (2, 1):
         for dev in (1, 0):

@@ -23,16 +23,11 @@ NIST = {
             intra=1.41483e7),
 }
 
-_npz = None
 _golden = None
 
 
 def nist_arrays(k, variant="reference"):
-    global _npz
-    if _npz is None:
-        _npz = np.load(os.path.join(GOLDEN, "spce_nist.npz"))
-    return mio.nist_system(float(_npz[f"box_{k}"]), _npz[f"xyz_{k}"], _npz[f"is_oxygen_{k}"],
-                           variant)
+    return mio.load_nist_fixture(k, variant)
 
 
 def golden(k, variant="reference"):

@@ -74,7 +74,8 @@ def main():
         data[f"is_oxygen_{k}"] = is_o
     b750, x750, o750 = mio.read_nist_text(f"{REF}/coord750.txt")
     assert b750 == data["box_4"] and np.array_equal(x750, data["xyz_4"]) and np.array_equal(o750, data["is_oxygen_4"])
-    np.savez_compressed(os.path.join(HERE, "spce_nist.npz"), **data)
+    np.savez_compressed(os.path.join(HERE, "..", "..", "metropolismontecarlo_amd", "data",
+                                     "spce_nist.npz"), **data)  # ships with the package
 
     for k in range(1, 5):
         for variant in ("reference", "unwrapped"):
