@@ -50,6 +50,26 @@
 # (GC.@preserve); nothing is cached by pointer (Loop() rebinds ewald.sumQExpOld/New on every move,
 # main.jl:621,628).
 #
+# ONE ccall PER REFERENCE CALL.  The per-molecule methods hand the library the caller's own arrays
+# (mmc_call_lj_poly_du / mmc_call_ewald_short / mmc_call_ewald_real / mmc_call_recip_move,
+# include/mmc_hip.h): the library compares molecule i and the molecule of the previous call with its
+# mirror, evaluates LJ and real-space Coulomb together on the context's persistent kernel, answers
+# the second of LJ_poly_ΔU(i) / EwaldShort(i) from that evaluation, computes RecipMove with the
+# evaluation of the moved molecule, and finds out by content which of its buffers
+# ewald.sumQExpOld / sumQExpNew are.  Measured through the Python mirror of this file (api.py, the
+# same library calls): 33 us for the five calls of one Loop() iteration at 750 molecules, against
+# 100 us for a C port of the reference on one core (bench.py, `call_surface`).
+#
+# BEYOND THE REFERENCE'S SURFACE (module MMCHipCore, nothing of Main is touched):
+#   MMCHipCore.trial_move / accept_move! / reject_move!   the five calls of one Loop() iteration as
+#       ONE evaluation (mmc_trial_move, mmc_accept_move, mmc_reject_move)
+#   MMCHipCore.Batch                                      R independent replicas of the system on
+#       one GPU (mmc_batch_*): north_star's "many independent NVT replicas fill the device" with
+#       accept/reject on the Julia host (eval! / settle!) or in the library's native driver
+#       (run! / run_chains!); see INTEGRATION.md.
+# tests/test_julia_binding.py parses include/mmc_hip.h and every ccall below and compares symbol,
+# arity and the C-to-Julia type of every argument, and the field layouts of the structs.
+#
 # NOT RUN.  The build image has no `julia` (and no network to fetch one), so this file has never
 # been executed; it is written against the reference's source and the C header it binds
 # (include/mmc_hip.h), and tests/test_julia_binding.py checks by text that every method above is
@@ -69,19 +89,56 @@ using StaticArrays
 
 const libmmc = get(ENV, "MMC_HIP_LIB", joinpath(@__DIR__, "..", "libmmc_hip.so"))
 
+# mirrors of the structs of include/mmc_hip.h (field order, types and padding are checked by
+# tests/test_julia_binding.py against the header)
 struct MMCTotals
     energy::Float64; virial::Float64; coulomb::Float64
     lj::Float64; real::Float64; recip::Float64; self::Float64
     n_overlap::Int32; _pad::Int32
 end
 
+struct MMCMove
+    mol::Int32; accept_prev::Int32
+    com_new::NTuple{3,Float64}
+    atoms_new::NTuple{9,Float64}
+end
+
+struct MMCMoveResult
+    d_lj::Float64; d_real::Float64; d_recip::Float64; d_vir::Float64
+    overlap::Int32; _pad::Int32
+end
+
+struct MMCRunParams
+    temperature::Float64; dr_max::Float64; dphi_max::Float64
+    seed::UInt64; n_steps::Int64
+    n_groups::Int32; n_parts::Int32; time_kernels::Int32; n_threads::Int32; n_streams::Int32; _pad::Int32
+    replica0::UInt64
+end
+
+struct MMCRunStats
+    moves::Int64; launches::Int64
+    trans_attempt::Int64; trans_accept::Int64; rot_attempt::Int64; rot_accept::Int64; overlaps::Int64
+    wall_ms::Float64; kernel_ms::Float64; energy_sum::Float64
+    timed_launches::Int64; torn_records::Int64; server_steps::Int64
+end
+
+struct MMCChain
+    dr_max::Float64; dphi_max::Float64
+    energy::Float64; virial::Float64
+    avg_energy::Float64; avg_virial::Float64
+    steps_taken::Int64; overlaps::Int64
+    trans_naccepp::Int64; trans_attempp::Int64; trans_naccept::Int64; trans_attempt::Int64
+    rot_naccepp::Int64; rot_attempp::Int64; rot_naccept::Int64; rot_attempt::Int64
+    trans_set_value::Float64; rot_set_value::Float64
+end
+
+"Address of the first Float64 of a Vector of bits types (SVector{3,Float64}, ComplexF64, Float64)."
+fptr(x) = Ptr{Float64}(pointer(x))
+
 mutable struct Session
     ctx::Ptr{Cvoid}
     box::Float64
-    last_mol::Int64
     ewald_key::Tuple
-    s_old::Vector{ComplexF64}   # host copies of what the device S buffers hold
-    s_new::Vector{ComplexF64}
 end
 
 const SESSION = Ref{Union{Nothing,Session}}(nothing)
@@ -101,11 +158,11 @@ function upload!(com, fa, la, coords, atype, charge, eps, sig, box::Float64, dev
         check(ccall((:mmc_upload_system, libmmc), Int32,
                     (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64},
                      Ptr{Int64}, Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Float64),
-                    ctx[], length(com), length(coords), pointer(com), pointer(fa), pointer(la),
-                    pointer(coords), pointer(atype), pointer(charge), size(eps, 1), pointer(eps),
+                    ctx[], length(com), length(coords), fptr(com), pointer(fa), pointer(la),
+                    fptr(coords), pointer(atype), pointer(charge), size(eps, 1), pointer(eps),
                     pointer(sig), box))
     end
-    SESSION[] = Session(ctx[], box, 0, (), ComplexF64[], ComplexF64[])
+    SESSION[] = Session(ctx[], box, ())
     return SESSION[]
 end
 
@@ -132,31 +189,12 @@ end
 
 session() = (s = SESSION[]; s === nothing ? error("MMCHipCore.attach!(...) first") : s)
 
-# Loop() changes COM[i] / coords[first:last] of ONE molecule between calls and may have restored
-# the previous one (main.jl:527,552,623-624): re-send both.
-function sync_molecule!(s::Session, com, coords, first_atom, i::Int64)
-    for m in unique((i, s.last_mol))
-        m == 0 && continue
-        f = first_atom(m)
-        GC.@preserve com coords begin
-            check(ccall((:mmc_set_molecule, libmmc), Int32,
-                        (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}),
-                        s.ctx, m, pointer(com, m), pointer(coords, f)))
-        end
-    end
-    s.last_mol = i
-end
-sync_molecule!(s::Session, moa, soa, i::Int64) =
-    sync_molecule!(s, moa.COM, soa.coords, m -> moa.firstAtom[m], i)
-sync_molecule_legacy!(s::Session, system, qq_r, i::Int64) =
-    sync_molecule!(s, system.rm, qq_r, m -> system.thisMol_theseAtoms[m][1], i)
-
+"Re-send every centre of mass and atom (after host edits that are not Loop()'s one-molecule pattern)."
 function sync_all!(s::Session, com, coords)
     GC.@preserve com coords begin
         check(ccall((:mmc_update_system, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-                    s.ctx, com === nothing ? C_NULL : pointer(com), pointer(coords)))
+                    s.ctx, com === nothing ? Ptr{Float64}(C_NULL) : fptr(com), fptr(coords)))
     end
-    s.last_mol = 0
 end
 
 function bind_ewald!(s::Session, kappa, nk, k_sq_max, factor, box)
@@ -167,51 +205,49 @@ function bind_ewald!(s::Session, kappa, nk, k_sq_max, factor, box)
                     (Ptr{Cvoid}, Float64, Int64, Int64, Float64, Float64, Ptr{Int64}),
                     s.ctx, kappa, nk, k_sq_max, box, factor, n))
         s.ewald_key = key
-        s.s_old = ComplexF64[]; s.s_new = ComplexF64[]   # device arrays were zeroed
     end
 end
 bind_ewald!(s::Session, ewald, box) =
     bind_ewald!(s, ewald.kappa, ewald.nk, ewald.k_sq_max, ewald.factor, box)
 
-# Loop rebinds ewald.sumQExpOld/New to fresh copies (main.jl:621,628): push them when the
-# arrays are not the ones the device mirrors.
-function push_s!(s::Session, ewald)
-    so, sn = ewald.sumQExpOld, ewald.sumQExpNew
-    # compare CONTENT (337 complex numbers): array identity can be recycled by the allocator
-    if so != s.s_old || sn != s.s_new
-        GC.@preserve so sn begin
-            check(ccall((:mmc_set_sumqexp, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-                        s.ctx, pointer(so), pointer(sn)))
-        end
-        s.s_old = copy(so); s.s_new = copy(sn)
-    end
-end
-
+"ewald.sumQExpOld / sumQExpNew <- the device's (RecipLong and potential write both, ewalds.jl:600-601)."
 function pull_s!(s::Session, ewald; old::Bool = false)
     so, sn = ewald.sumQExpOld, ewald.sumQExpNew
     GC.@preserve so sn begin
         check(ccall((:mmc_get_sumqexp, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}),
-                    s.ctx, old ? pointer(so) : C_NULL, pointer(sn)))
+                    s.ctx, old ? fptr(so) : Ptr{Float64}(C_NULL), fptr(sn)))
     end
-    if old
-        s.s_old = copy(so)
-    end
-    s.s_new = copy(sn)
 end
 
-function lj_poly_du(s::Session, i::Int64, r_cut::Float64)
+# ---- the per-molecule calls with the caller's own arrays: one ccall each ----
+function call_lj_poly_du(s::Session, i::Int64, com, coords, r_cut::Float64)
     pot = Ref{Float64}(0.0); vir = Ref{Float64}(0.0)
-    check(ccall((:mmc_lj_poly_du, libmmc), Int32,
-                (Ptr{Cvoid}, Int64, Float64, Ptr{Float64}, Ptr{Float64}), s.ctx, i, r_cut, pot, vir))
+    GC.@preserve com coords begin
+        check(ccall((:mmc_call_lj_poly_du, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}),
+                    s.ctx, i, fptr(com), fptr(coords), r_cut, pot, vir))
+    end
     return pot[], vir[]
 end
 
-function ewald_real(s::Session, i::Int64, r_cut::Float64, ovr::Float64)
+function call_ewald_real(s::Session, i::Int64, com, coords, r_cut::Float64, ovr::Float64)
     pot = Ref{Float64}(0.0); ov = Ref{Int32}(0)
-    check(ccall((:mmc_ewald_real, libmmc), Int32,
-                (Ptr{Cvoid}, Int64, Float64, Float64, Ptr{Float64}, Ptr{Int32}),
-                s.ctx, i, r_cut, ovr, pot, ov))
+    GC.@preserve com coords begin
+        check(ccall((:mmc_call_ewald_real, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ptr{Float64}, Ptr{Int32}),
+                    s.ctx, i, fptr(com), fptr(coords), r_cut, ovr, pot, ov))
+    end
     return pot[], ov[] != 0
+end
+
+function call_ewald_short(s::Session, i::Int64, com, coords, qq_rcut::Float64)
+    e = Ref{Float64}(0.0); v = Ref{Float64}(0.0); ov = Ref{Int32}(0)
+    GC.@preserve com coords begin
+        check(ccall((:mmc_call_ewald_short, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                    s.ctx, i, fptr(com), fptr(coords), qq_rcut, e, v, ov))
+    end
+    return e[], v[], ov[] != 0
 end
 
 function recip_long(s::Session, ewald)
@@ -231,6 +267,178 @@ function totals(s::Session, sym::Symbol, lj_rcut::Float64, qq_rcut::Float64)
                     (Ptr{Cvoid}, Float64, Float64, Ptr{MMCTotals}), s.ctx, lj_rcut, qq_rcut, t))
     end
     return t[]
+end
+
+# ---- one Loop() iteration as ONE evaluation (main.jl:491-593) ----
+"""
+    d, overlap = trial_move(i, com_new, atoms_new, lj_rcut, qq_rcut)
+
+The five hot-path calls of one Loop() iteration for molecule `i` moved to `com_new` /
+`atoms_new` (3 atoms): d = (ΔLJ, Δreal, ΔRecip, Δvirial) as `partial_new - partial_old` builds
+them (main.jl:593,600-601).  The device keeps the OLD state: follow with `accept_move!()`
+(main.jl:598-621) or `reject_move!()` (:622-629).  The host arrays are the caller's business.
+"""
+function trial_move(i::Int64, com_new::SVector{3,Float64}, atoms_new::Vector{SVector{3,Float64}},
+                    lj_rcut::Float64, qq_rcut::Float64)
+    s = session()
+    d = zeros(Float64, 4); ov = Ref{Int32}(0); cn = [com_new]
+    GC.@preserve cn atoms_new d begin
+        check(ccall((:mmc_trial_move, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Ptr{Float64}, Ptr{Int32}),
+                    s.ctx, i, fptr(cn), fptr(atoms_new), lj_rcut, qq_rcut, pointer(d), ov))
+    end
+    return (d[1], d[2], d[3], d[4]), ov[] != 0
+end
+accept_move!() = check(ccall((:mmc_accept_move, libmmc), Int32, (Ptr{Cvoid},), session().ctx))
+reject_move!() = check(ccall((:mmc_reject_move, libmmc), Int32, (Ptr{Cvoid},), session().ctx))
+
+"Counters of the context (mmc_ctx_stats): commands served, launches, retries, cache hits, ..."
+function stats()
+    out = zeros(Int64, 8)
+    check(ccall((:mmc_ctx_stats, libmmc), Int32, (Ptr{Cvoid}, Ptr{Int64}), session().ctx, out))
+    return out
+end
+
+# =================================================================================================
+# The replica batch: R independent NVT chains of the attached kind of system on one GPU
+# (include/mmc_hip.h, "replica batch").  Molecules must have 3 atoms (RecipMove, ewalds.jl:740).
+# =================================================================================================
+mutable struct Batch
+    h::Ptr{Cvoid}
+    n_replicas::Int64
+    n_mol::Int64
+end
+
+"""
+    b = Batch(n_replicas, moa, soa, vdwTable, ewald, box, lj_rcut, qq_rcut; device = 0)
+
+Every replica starts from (moa, soa); `ewald` supplies kappa, nk, k_sq_max and factor
+(main.jl:285-303).  Call `potential_ewald(b)` (or `recip_long!(b)`) once before the first move: it
+fills the structure factors.
+"""
+function Batch(n_replicas::Integer, moa, soa, vdwTable, ewald, box::Float64, lj_rcut::Float64,
+               qq_rcut::Float64; device::Integer = 0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    com, coords, atype, charge = moa.COM, soa.coords, soa.atype, soa.charge
+    eps, sig = vdwTable.ϵᵢⱼ, vdwTable.σᵢⱼ
+    GC.@preserve com coords atype charge eps sig begin
+        check(ccall((:mmc_batch_create, libmmc), Int32,
+                    (Int32, Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Int64},
+                     Ptr{Float64}, Int64, Ptr{Float64}, Ptr{Float64}, Float64, Float64, Int64, Int64,
+                     Float64, Float64, Float64, Ptr{Ptr{Cvoid}}),
+                    device, C_NULL, n_replicas, length(com), fptr(com), fptr(coords), pointer(atype),
+                    pointer(charge), size(eps, 1), pointer(eps), pointer(sig), box, ewald.kappa,
+                    ewald.nk, ewald.k_sq_max, ewald.factor, lj_rcut, qq_rcut, h))
+    end
+    b = Batch(h[], n_replicas, length(com))
+    finalizer(close!, b)
+    return b
+end
+
+function close!(b::Batch)
+    b.h == C_NULL && return
+    ccall((:mmc_batch_destroy, libmmc), Int32, (Ptr{Cvoid},), b.h)
+    b.h = C_NULL
+    return
+end
+
+"Tuning switches of include/mmc_hip.h (\"kernel\", \"parts\", \"device_moves\", \"persistent\", ...)."
+set_option!(b::Batch, key::String, value::Integer) =
+    check(ccall((:mmc_batch_set_option, libmmc), Int32, (Ptr{Cvoid}, Cstring, Int64), b.h, key, value))
+
+"potential(..., \"ewald\") of every replica (energy.jl:946-1032)."
+function potential_ewald(b::Batch)
+    tot = Vector{MMCTotals}(undef, b.n_replicas)
+    check(ccall((:mmc_batch_potential_ewald, libmmc), Int32, (Ptr{Cvoid}, Ptr{MMCTotals}), b.h, tot))
+    return tot
+end
+
+"RecipLong of every replica; energies WITHOUT factor (ewalds.jl:603)."
+function recip_long!(b::Batch)
+    e = Vector{Float64}(undef, b.n_replicas)
+    check(ccall((:mmc_batch_recip_long, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}), b.h, e))
+    return e
+end
+
+"""
+    eval!(b, moves, results)
+
+One trial move per replica in one launch: `moves[r]` (molecule, new COM and atoms;
+`accept_prev` settles the replica's previous proposal first, main.jl:598-629) -> `results[r]`
+(ΔLJ, Δreal, ΔRecip, Δvirial, overlap).  Accept/reject stays with the caller: this is Loop()'s
+body for R chains at once.
+"""
+function eval!(b::Batch, moves::Vector{MMCMove}, results::Vector{MMCMoveResult})
+    length(moves) == b.n_replicas == length(results) || error("one move and one result per replica")
+    check(ccall((:mmc_batch_eval, libmmc), Int32, (Ptr{Cvoid}, Ptr{MMCMove}, Ptr{MMCMoveResult}),
+                b.h, moves, results))
+    return results
+end
+
+"Settle the last proposals (accept[r] != 0: commit, main.jl:598-621) without evaluating new ones."
+function settle!(b::Batch, accept::Vector{Int32})
+    length(accept) == b.n_replicas || error("one flag per replica")
+    check(ccall((:mmc_batch_settle, libmmc), Int32, (Ptr{Cvoid}, Ptr{Int32}), b.h, accept))
+end
+
+"""
+    stats = run!(b, params, energies)
+
+The library's native driver: Loop()'s sequential accept/reject (main.jl:487-644) for every
+replica, `params.n_steps` trial moves each; `energies[r]` is the running total.energy (:599).
+"""
+function run!(b::Batch, params::MMCRunParams, energies::Vector{Float64})
+    length(energies) == b.n_replicas || error("one energy per replica")
+    p = Ref(params); st = Ref{MMCRunStats}()
+    check(ccall((:mmc_batch_run, libmmc), Int32,
+                (Ptr{Cvoid}, Ptr{MMCRunParams}, Ptr{Float64}, Ptr{MMCRunStats}), b.h, p, energies, st))
+    return st[]
+end
+
+"As `run!`, every chain with its own step sizes, block accumulators and Adjust! (adjust.jl:1-83)."
+function run_chains!(b::Batch, params::MMCRunParams, chains::Vector{MMCChain}, adjust::Bool)
+    length(chains) == b.n_replicas || error("one chain record per replica")
+    p = Ref(params); st = Ref{MMCRunStats}()
+    check(ccall((:mmc_batch_run_chains, libmmc), Int32,
+                (Ptr{Cvoid}, Ptr{MMCRunParams}, Ptr{MMCChain}, Int32, Ptr{MMCRunStats}),
+                b.h, p, chains, adjust ? 1 : 0, st))
+    return st[]
+end
+
+"Coordinates (and sumQExpOld) of replica r (0-based, like the library)."
+function get_replica(b::Batch, r::Integer)
+    com = Vector{SVector{3,Float64}}(undef, b.n_mol)
+    coords = Vector{SVector{3,Float64}}(undef, 3 * b.n_mol)
+    s_old = Vector{ComplexF64}(undef, 337)
+    GC.@preserve com coords s_old begin
+        check(ccall((:mmc_batch_get_replica, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                    b.h, r, fptr(com), fptr(coords), fptr(s_old)))
+    end
+    return com, coords, s_old
+end
+
+function set_replica!(b::Batch, r::Integer, com::Vector{SVector{3,Float64}},
+                      coords::Vector{SVector{3,Float64}})
+    GC.@preserve com coords begin
+        check(ccall((:mmc_batch_set_replica, libmmc), Int32,
+                    (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}), b.h, r, fptr(com), fptr(coords)))
+    end
+end
+
+"The device part of an NPT volume move for every replica (volumeChange.jl:59-80)."
+volume_change!(b::Batch, new_box::Float64, new_kappa::Float64) =
+    check(ccall((:mmc_batch_volume_change, libmmc), Int32, (Ptr{Cvoid}, Float64, Float64),
+                b.h, new_box, new_kappa))
+
+"Status line of one block as Loop() prints it (main.jl:667-679) from one chain record."
+function block_line(chain::MMCChain, block::Integer, n_mol::Integer, box::Float64;
+                    ideal_term::Float64 = 4.60453)
+    buf = Vector{UInt8}(undef, 512); c = Ref(chain)
+    check(ccall((:mmc_chain_block_line, libmmc), Int32,
+                (Ptr{MMCChain}, Int64, Int64, Float64, Float64, Ptr{UInt8}, Int64),
+                c, block, n_mol, box, ideal_term, buf, length(buf)))
+    return unsafe_string(pointer(buf))
 end
 
 end # module MMCHipCore
@@ -254,7 +462,7 @@ function PrepareEwaldVariables(ewald::EWALD, boxSize::Real where {T})
     cfac = Vector{Float64}(undef, n[])
     GC.@preserve kxyz cfac begin
         C.check(ccall((:mmc_get_kvectors, C.libmmc), Int32, (Ptr{Cvoid}, Ptr{Int32}, Ptr{Float64}),
-                      ctx[], pointer(kxyz), pointer(cfac)))
+                      ctx[], Ptr{Int32}(pointer(kxyz)), pointer(cfac)))
     end
     ccall((:mmc_ctx_destroy, C.libmmc), Int32, (Ptr{Cvoid},), ctx[])
     return EWALD(ewald.kappa, ewald.nk, ewald.k_sq_max, oftype(ewald.nk, n[]), kxyz, cfac,
@@ -264,14 +472,12 @@ end
 # ---- Ewald/energy.jl:209-210 ----------------------------------------------------------------------
 function LJ_poly_ΔU(i, moa::StructArray, soa::StructArray,
                             vdwTable, r_cut, box)
-    s = MMCHipCore.session(); MMCHipCore.sync_molecule!(s, moa, soa, Int64(i))
-    return MMCHipCore.lj_poly_du(s, Int64(i), Float64(r_cut))
+    return MMCHipCore.call_lj_poly_du(MMCHipCore.session(), Int64(i), moa.COM, soa.coords, Float64(r_cut))
 end
 
 # ---- Ewald/energy.jl:126 (legacy) -----------------------------------------------------------------
 function LJ_poly_ΔU(i::Int, system::Requirements)
-    s = MMCHipCore.session(); MMCHipCore.sync_molecule_legacy!(s, system, system.ra, Int64(i))
-    return MMCHipCore.lj_poly_du(s, Int64(i), system.r_cut)
+    return MMCHipCore.call_lj_poly_du(MMCHipCore.session(), Int64(i), system.rm, system.ra, system.r_cut)
 end
 
 # ---- Ewald/ewalds.jl:293-299 ----------------------------------------------------------------------
@@ -283,8 +489,7 @@ function EwaldReal(chosenOne::Int64,
                     box::Float64
     )
     s = MMCHipCore.session(); MMCHipCore.bind_ewald!(s, ewald, box)
-    MMCHipCore.sync_molecule!(s, moa, soa, chosenOne)
-    return MMCHipCore.ewald_real(s, chosenOne, r_cut, 0.5)         # ovr = 0.5 (ewalds.jl:327)
+    return MMCHipCore.call_ewald_real(s, chosenOne, moa.COM, soa.coords, r_cut, 0.5)  # ovr = 0.5 (ewalds.jl:327)
 end
 
 # ---- Ewald/ewalds.jl:205-213 (legacy: ovr = 1.0, cutoff from system.r_cut) --------------------------
@@ -299,8 +504,7 @@ function EwaldReal(
 )
     s = MMCHipCore.session()
     MMCHipCore.bind_ewald!(s, Float64(kappa), 5, 27, factor, box)  # `factor`: constants.jl:28
-    MMCHipCore.sync_molecule_legacy!(s, system, qq_r, chosenOne)
-    return MMCHipCore.ewald_real(s, chosenOne, system.r_cut, 1.0)  # ovr = 1.0 (ewalds.jl:240)
+    return MMCHipCore.call_ewald_real(s, chosenOne, system.rm, qq_r, system.r_cut, 1.0)  # ovr = 1.0 (ewalds.jl:240)
 end
 
 # ---- Ewald/ewalds.jl:892-899 ----------------------------------------------------------------------
@@ -312,13 +516,8 @@ function EwaldShort(
     ewald::EWALD,
     box::Float64,
 )
-    C = MMCHipCore
-    s = C.session(); C.bind_ewald!(s, ewald, box); C.sync_molecule!(s, moa, soa, i)
-    e = Ref{Float64}(0.0); v = Ref{Float64}(0.0); ov = Ref{Int32}(0)
-    C.check(ccall((:mmc_ewald_short, C.libmmc), Int32,
-                  (Ptr{Cvoid}, Int64, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
-                  s.ctx, i, sim_props.qq_rcut, e, v, ov))
-    return e[], v[], ov[] != 0
+    s = MMCHipCore.session(); MMCHipCore.bind_ewald!(s, ewald, box)
+    return MMCHipCore.call_ewald_short(s, i, moa.COM, soa.coords, sim_props.qq_rcut)
 end
 
 # ---- Ewald/ewalds.jl:848-856 (legacy) -------------------------------------------------------------
@@ -369,17 +568,18 @@ function RecipMove(
     qq_q::Vector,
 )
     C = MMCHipCore
-    s = C.session(); C.bind_ewald!(s, ewalds, box); C.push_s!(s, ewalds)
+    s = C.session(); C.bind_ewald!(s, ewalds, box)
     ro = Vector{SVector{3,Float64}}(r_old); rn = Vector{SVector{3,Float64}}(r_new)
     q = Vector{Float64}(qq_q)
+    so, sn = ewalds.sumQExpOld, ewalds.sumQExpNew   # as they are NOW: Loop rebinds them (main.jl:621,628)
     de = Ref{Float64}(0.0)
-    GC.@preserve ro rn q begin
-        C.check(ccall((:mmc_recip_move, C.libmmc), Int32,
-                      (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64}),
-                      s.ctx, pointer(ro), pointer(rn), pointer(q), length(q), de))
+    GC.@preserve ro rn q so sn begin
+        C.check(ccall((:mmc_call_recip_move, C.libmmc), Int32,
+                      (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ptr{Float64},
+                       Ptr{Float64}, Ptr{Float64}),
+                      s.ctx, C.fptr(ro), C.fptr(rn), pointer(q), length(q), C.fptr(so), C.fptr(sn), de))
     end
-    C.pull_s!(s, ewalds)                        # sumQExpNew was updated in place (:805-814)
-    return de[], ewalds
+    return de[], ewalds                         # sumQExpNew was updated in place (:805-814)
 end
 
 # ---- Ewald/ewalds.jl:829 --------------------------------------------------------------------------
@@ -400,7 +600,7 @@ function CoulombReal(
     system::Requirements
 )
     C = MMCHipCore
-    s = C.session(); C.sync_molecule_legacy!(s, system, qq_r, chosenOne)
+    s = C.session(); C.sync_all!(s, system.rm, qq_r)
     pot = Ref{Float64}(0.0); ov = Ref{Int32}(0)
     # `@assert r_cut == 10.0` (energy.jl:648) comes back as status 2 -> AssertionError
     C.check(ccall((:mmc_coulomb_real, C.libmmc), Int32,
