@@ -117,8 +117,15 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
     const uint16_t *const cq_base = bv.comq;
     PartOut *const part_dst = out + part;
 
+#ifdef CS_PROFILE // diagnostic build: 10 ns ticks per phase, summed over the commands (state[16 + 8 wave + k])
+    unsigned long long cp[6] = { 0, 0, 0, 0, 0, 0 }, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#define CS_T(x) x = __builtin_amdgcn_s_memrealtime()
+#else
+#define CS_T(x)
+#endif
     for (unsigned long long seq = sa.seq0;; seq++) {
         asm volatile("" : "+v"(lane)); // keep lane-derived values out of LICM (see k_move_eval_wave)
+        CS_T(c0);
         unsigned long long *const cw = cmdw[seq & 1];
         // ---- wave 0: wait for the command (bounded), copy the block to LDS, refresh stale molecules ----
         if (wv == 0) {
@@ -172,9 +179,16 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
                 }
             }
         }
+        CS_T(c1);
         __syncthreads(); // the block is in LDS, wave 0's stores are complete
+        CS_T(c2);
         const unsigned long long head = cw[CS_W_HEAD];
         const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)head) & 0xffffu;
+#ifdef CS_PROFILE
+        if ((flags & CS_QUIT) && lane == 0 && blockIdx.x == 0)
+            for (int q = 0; q < 6; q++)
+                sa.state[16 + 8 * wv + q] = (int32_t)cp[q];
+#endif
         if (flags & CS_QUIT)
             return;
         const unsigned long long wmol = cw[CS_PHYS(CS_W_MOL)], wsb = cw[CS_PHYS(CS_W_SBUF)];
@@ -205,6 +219,11 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
 #include "mmc_wave_unit.inc"
 #undef WV_NS
         }
+#ifdef CS_PROFILE
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        CS_T(c3);
+        if (flags & CS_EVAL) { cp[0] += c1 - c0; cp[1] += c2 - c1; cp[2] += c3 - c2; cp[3] += 1; }
+#endif
 #undef WV_S_MIRROR
 #undef WV_S_DST
 #undef WV_S_BASE

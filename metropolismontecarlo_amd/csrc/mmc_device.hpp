@@ -170,6 +170,38 @@ __device__ __forceinline__ double wave_sum(double v)
     return v; // lane 0 holds the sum
 }
 
+// ---- DPP forms (no LDS crossbar): for the latency kernels, where a ds_bpermute tree of six sums is
+// a visible part of a unit's critical path.  row_shr:N = lane i reads lane i - N of its row of 16
+// lanes, 0 beyond the start of the row.
+template <int N> __device__ __forceinline__ int dpp_row_shr(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + N, 0xf, 0xf, true);
+}
+template <int N> __device__ __forceinline__ double dpp_row_shr_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)dpp_row_shr<N>((int)b), hi = (unsigned)dpp_row_shr<N>((int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// Sum over the 64 lanes, the total in EVERY lane (wave-uniform): an inclusive scan inside each row
+// of 16 (1, 2, 4, 8), then the four row totals added in row order.  Fixed order -> reproducible.
+__device__ __forceinline__ double wave_sum_rows(double v)
+{
+    v += dpp_row_shr_f64<1>(v);
+    v += dpp_row_shr_f64<2>(v);
+    v += dpp_row_shr_f64<4>(v);
+    v += dpp_row_shr_f64<8>(v);
+    const long long b = __double_as_longlong(v);
+    double r[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, 16 * k + 15);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 16 * k + 15);
+        r[k] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
 // Sum NV values over the 256-thread workgroup; thread 0 gets the totals in out[].
 // red: LDS scratch of NV * MMC_WAVES doubles.  Fixed order -> bitwise reproducible.
 template <int NV>

@@ -3,6 +3,7 @@
 #include "../../include/mmc_hip.h"
 #include "mmc_total.hpp"
 #include "mmc_wave.hpp"
+#include "mmc_lat.hpp"
 #include <string>
 #include <vector>
 

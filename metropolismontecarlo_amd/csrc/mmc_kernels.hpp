@@ -373,19 +373,44 @@ __device__ inline void store_part(PartOut *dst, const double *w8, int tid)
     }
 }
 
-// 31-bit checksum of a PartOut's seven sums and its launch stamp (FNV-1a over the 14 dwords with an
-// extra xor-shift per double); the same function on the device (writer) and the host (reader).
+// 31-bit checksum of a PartOut's seven sums and its launch stamp: every word is hashed with its
+// position and the stamp on its own, the seven hashes are ADDED and the sum is folded -- so seven
+// lanes can hash in parallel (part_checksum_lanes) where one lane walking a serial chain over the
+// 14 dwords cost ~110 dependent instructions per record.  A record whose pieces come from two
+// launches has at least one word whose hash belongs to another (value, stamp): the sum differs
+// except with probability 2^-31.  The same function on the device (writer) and the host (reader).
+__host__ __device__ inline uint32_t part_word_hash(uint32_t lo, uint32_t hi, int k, unsigned stamp)
+{
+    uint32_t h = (lo ^ (0x9E3779B1u * (uint32_t)(k + 1))) * 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h = (h ^ hi ^ ((stamp & MMC_STAMP_MASK) * 0xC2B2AE35u)) * 0x27D4EB2Fu;
+    h ^= h >> 15;
+    return h;
+}
+__host__ __device__ inline uint32_t part_checksum_fold(uint32_t c)
+{
+    c ^= c >> 16;
+    return c & 0x7fffffffu;
+}
 __host__ __device__ inline uint32_t part_checksum(const double *w7, unsigned stamp)
 {
-    uint32_t c = 0x811C9DC5u ^ ((stamp & MMC_STAMP_MASK) * 0x9E3779B1u);
+    uint32_t c = 0;
     for (int k = 0; k < 7; k++) {
         unsigned long long b;
         __builtin_memcpy(&b, &w7[k], 8);
-        c = (c ^ (uint32_t)b) * 0x01000193u;
-        c = (c ^ (uint32_t)(b >> 32)) * 0x01000193u;
-        c ^= c >> 15;
+        c += part_word_hash((uint32_t)b, (uint32_t)(b >> 32), k, stamp);
     }
-    return c & 0x7fffffffu;
+    return part_checksum_fold(c);
+}
+// The same by the lanes of a wave: lane k < 7 holds word k in `word`; every lane gets the checksum.
+__device__ __forceinline__ uint32_t part_checksum_lanes(double word, int lane, unsigned stamp)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(word);
+    int h = lane < 7 ? (int)part_word_hash((uint32_t)b, (uint32_t)(b >> 32), lane, stamp) : 0;
+    h += dpp_row_shr<1>(h);
+    h += dpp_row_shr<2>(h);
+    h += dpp_row_shr<4>(h);
+    return part_checksum_fold((uint32_t)__builtin_amdgcn_readlane(h, 7));
 }
 
 // word 7 of the record: ovl[0] = checksum << 1 | overlap_old, ovl[1] = stamp << 1 | overlap_new

@@ -581,7 +581,8 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
                     v = __hip_atomic_load(sa.ctrl + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32)
                     | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-                if ((c >> 40) == (unsigned long long)(step + 1) || (c & SRV_QUIT))
+                // (the word carries the sequence number modulo 2^24: compare modulo 2^24)
+                if ((c >> 40) == ((unsigned long long)(step + 1) & 0xffffffULL) || (c & SRV_QUIT))
                     break; // (a host that gives up early posts "quit" with whatever sequence number)
                 if ((spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > SRV_TIMEOUT_TICKS) {
                     if (lane == 0) { // what this workgroup was waiting for, for the host's message

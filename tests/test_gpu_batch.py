@@ -103,6 +103,55 @@ def test_batch_eval_chain(k, variant, parts, kernel, orc):
                 assert rel(tot[r][key], to[key]) < TOL, (r, key)
 
 
+@pytest.mark.parametrize("k,variant,parts", [(1, "reference", 4), (1, "reference", 16),
+                                             (4, "unwrapped", 16), (4, "reference", 8),
+                                             (2, "unwrapped", 12), (3, "reference", 8)])
+def test_batch_eval_chain_latency_kernel(k, variant, parts, orc):
+    """test_batch_eval_chain for kernel 4 (k_move_eval_lat: resident molecule ranges, three lanes
+    to a neighbour, the reciprocal sum split over waves, one record per workgroup): diverging
+    replicas against three oracle chains, dU terms, overlap flags, final state."""
+    a = common.nist_arrays(k, variant)
+    moves = list(common.golden(k, variant)["moves"])
+    extra = dict(moves[0])
+    extra["com_new"] = (np.array(extra["com_new"]) + 0.05).tolist()
+    extra["atoms_new"] = (np.array(extra["atoms_new"]) + 0.05).tolist()
+    moves.insert(1, extra)
+    rules = [lambda n, ov: True, lambda n, ov: False, lambda n, ov: n % 2 == 0]
+    chains = [oracle_chain(orc, a, moves, r) for r in rules]
+    R = len(rules)
+    with make_batch(a, R) as b:
+        b.set_option("kernel", 4)
+        b.set_parts(parts)
+        b.recip_long()
+        acc_prev = np.zeros(R, dtype=bool)
+        for n, mv in enumerate(moves):
+            d, ov = b.eval(mv["mol"], np.tile(mv["com_new"], (R, 1)),
+                           np.tile(np.array(mv["atoms_new"]).ravel(), (R, 1)), acc_prev)
+            for r in range(R):
+                do, ovo, acco = chains[r][0][n]
+                assert ov[r] == ovo, (n, r)
+                assert np.abs(d[r] - do).max() < TOL * (np.abs(do).max() + 1e4), (n, r, d[r], do)
+                acc_prev[r] = acco
+        b.settle(acc_prev)
+        for r in range(R):
+            com, coords, S = b.get_replica(r)
+            _, s, ewr = chains[r]
+            assert np.array_equal(com, s.com) and np.array_equal(coords, s.coords), r
+            assert np.abs(S - ewr.sumQExpOld).max() < 1e-11 * np.abs(ewr.sumQExpOld).max(), r
+
+
+def test_latency_kernel_refuses_ranges_it_cannot_hold():
+    from metropolismontecarlo_amd._lib import MMCError
+    a = common.nist_arrays(4, "unwrapped")            # 750 molecules: 4 parts = 3 ranges of 250
+    mv = common.golden(4, "unwrapped")["moves"][0]
+    with make_batch(a, 1) as b:
+        b.set_option("kernel", 4)
+        b.set_parts(4)
+        b.recip_long()
+        with pytest.raises(MMCError, match="kernel 4 needs"):
+            b.eval(mv["mol"], np.tile(mv["com_new"], (1, 1)), np.tile(np.array(mv["atoms_new"]).ravel(), (1, 1)))
+
+
 def test_batch_parts_agree(orc):
     """The split of a move over 1..16 workgroups changes only the summation order."""
     a = common.nist_arrays(4, "unwrapped")

@@ -71,6 +71,47 @@ def test_server_equals_launch_per_step(k, R, steps, threads):
     assert same(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("k,R,parts,steps", [(4, 1, 16, 400), (4, 2, 8, 150), (1, 1, 8, 230),
+                                             (2, 3, 12, 90), (4, 1, 12, 300)])
+def test_latency_server_equals_launch_per_step(k, R, parts, steps):
+    """The latency server (k_move_server_lat: parts / 4 workgroups per replica, each reading the
+    replica's control word itself and keeping its own copy of its molecules) against
+    k_move_eval_lat launched per step with the same part count: identical chains bit for bit,
+    over two calls (random streams and S-buffer parity continue)."""
+    a = common.nist_arrays(k, "unwrapped")
+    res = []
+    for persistent in (1, 0):
+        with make_batch(a, R, persistent, kernel=4) as b:
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            stats = []
+            for n in (steps, 41):
+                e, st = b.run(n, 298.15, 0.316555789, 0.05, 17, e, n_groups=1, n_parts=parts)
+                stats.append([st[q] for q in ("moves", "trans_accept", "rot_accept", "overlaps")])
+            assert st["torn_records"] == 0 and st["server_steps"] == (41 if persistent else 0)
+            e2 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e - e2).max() <= 1e-11 * np.abs(e2).max()
+            res.append((e, stats, state(b)))
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+    assert res[0][1][0][1] + res[0][1][0][2] > 0
+    assert same(res[0][2], res[1][2])
+
+
+def test_single_chain_takes_the_latency_server_by_default():
+    """One chain (BASELINE configs[1]): the automatic choice is the latency server with four
+    workgroups; it samples the same chain as an explicit request for it."""
+    a = common.nist_arrays(4, "unwrapped")
+    res = []
+    for kernel, parts in ((3, 0), (4, 16)):
+        with make_batch(a, 1, -1, kernel=kernel) as b:
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            e, st = b.run(300, 298.15, 0.316555789, 0.05, 5, e, n_groups=1, n_parts=parts)
+            assert st["server_steps"] == 300
+            e2 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e - e2).max() <= 1e-11 * np.abs(e2).max()
+            res.append((e, state(b)))
+    assert np.array_equal(res[0][0], res[1][0]) and same(res[0][1], res[1][1])
+
+
 def test_server_chains_with_step_adjustment():
     """mmc_batch_run_chains with Adjust! every sweep (adjust.jl:1-83): the server re-reads the step
     sizes when told to and re-draws its speculative proposal."""
