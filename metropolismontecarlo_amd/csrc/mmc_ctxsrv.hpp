@@ -30,6 +30,7 @@
 // relaunching it, and relaunches (replaying the idempotent command) whenever a reply is late.
 #pragma once
 #include "mmc_wave.hpp"
+#include "mmc_lat.hpp"
 
 #define CS_MAX_PEND 2
 #define CS_EVAL 1u   // pair part: LJ + real-space Coulomb of molecule `mol`
@@ -230,5 +231,137 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
 #undef WV_STORE_WT
 #undef WV_PART_DST
 #undef WV_CQ_BASE
+    }
+}
+
+// =================================================================================================
+// k_ctx_server_lat: the same protocol on the latency unit body (mmc_wave_lat.inc, mmc_lat.hpp):
+// G workgroups of four waves, each wave a part with its molecule range resident; one combined
+// record per workgroup (out[g]), and -- for commands with a reciprocal part -- the integrity sum of
+// the mirrored S_new of the workgroup's reciprocal waves in a second record (out[8 + g]).
+// =================================================================================================
+__global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
+    BatchView bv, double *rec, const double *__restrict__ qq_tab,
+    const int32_t *__restrict__ kpack, FastConsts fc, PartOut *out, int n_parts, PairParams pp,
+    CtxSrvArgs sa)
+{
+    __shared__ __align__(16) LatShared ls;
+    __shared__ __align__(16) unsigned long long cmdw[2][64];
+    const int tid = threadIdx.x, lane0 = tid & 63;
+    int lane = lane0;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += LAT_WAVES * 64)
+        ls.qtab[k] = qq_tab[k];
+    const int r = 0, g = blockIdx.x;
+    double *const myrec = rec;
+    const uint16_t *const cq_base = bv.comq;
+    LAT_WAVE_SETUP(g * LAT_WAVES + wv, myrec, cq_base)
+    __syncthreads();
+    const bool wg_has_recip = (g + 1) * LAT_WAVES > plan.np;
+
+    for (unsigned long long seq = sa.seq0;; seq++) {
+        asm volatile("" : "+v"(lane));
+        unsigned long long *const cw = cmdw[seq & 1];
+        if (wv == 0) { // the command block: one load per lane, head + eight tags (see k_ctx_server)
+            unsigned long long v = 0, head = 0;
+            const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+            bool gave_up = false;
+            for (unsigned spins = 1;; spins++) {
+                v = __hip_atomic_load(sa.cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                head = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32)
+                       | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+                if (head & CS_QUIT)
+                    break;
+                const bool mine_ok = (lane & 7) != 7 || v == seq;
+                if ((head >> 16) == seq && wave_ballot(mine_ok) == ~0ULL)
+                    break;
+                if ((spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > CS_IDLE_TICKS) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (gave_up || (head & CS_QUIT)) {
+                if (lane == 0) {
+                    __hip_atomic_store(sa.state + 1 + g, gave_up ? 1 : 2, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (gave_up)
+                        __hip_atomic_store(sa.state, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    cw[CS_W_HEAD] = CS_QUIT;
+                }
+            } else {
+                cw[lane] = v;
+            }
+        }
+        __syncthreads(); // the block is in LDS (and every wave is done with the previous command's LDS)
+        const unsigned long long head = cw[CS_W_HEAD];
+        const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)head) & 0xffffu;
+        if (flags & CS_QUIT)
+            return;
+        // molecules whose device copy is stale: every wave refreshes its resident range, one wave
+        // of the workgroup writes the global copies
+        {
+            const int n_pend = __builtin_amdgcn_readfirstlane((int)(cw[CS_PHYS(CS_W_MOL)] >> 32));
+            const unsigned long long pmw = cw[CS_PHYS(CS_W_PMOL)];
+            for (int p = 0; p < n_pend && p < CS_MAX_PEND; p++) {
+                const int pm = __builtin_amdgcn_readfirstlane(p == 0 ? (int)pmw : (int)(pmw >> 32));
+                const double val = lane < 12
+                    ? __longlong_as_double((long long)cw[CS_PHYS(CS_W_PREC + 12 * p + lane)]) : 0.0;
+                LAT_REFRESH(pm, val);
+                if (wv == 0)
+                    LAT_COMMIT_GLOBAL(0, pm, val, myrec);
+            }
+        }
+        const unsigned long long wmol = cw[CS_PHYS(CS_W_MOL)], wsb = cw[CS_PHYS(CS_W_SBUF)];
+        const int i0 = __builtin_amdgcn_readfirstlane((int)wmol);
+        const int sbits = __builtin_amdgcn_readfirstlane((int)wsb);
+        const unsigned stamp = (unsigned)__builtin_amdgcn_readfirstlane((int)(wsb >> 32)) & MMC_STAMP_MASK;
+        const int s_base = sbits & 0xff, s_dst = (sbits >> 8) & 0xff;
+        double w = 0.0; // the move record, lane t = word t
+        if (lane < MV_Q_NEW)
+            w = __longlong_as_double((long long)cw[CS_PHYS(CS_W_MV + lane)]);
+        double *const s_mirror = sa.s_mirror + (int64_t)s_dst * bv.nk_stride * 2;
+        unsigned long long s_sum_out = 0;
+        {
+            const bool part_pairs = do_pairs, part_recip = do_recip;
+            const bool do_pairs = part_pairs && (flags & CS_EVAL);   // (shadow: what THIS command wants)
+            const bool do_recip = part_recip && (flags & CS_RECIP);
+#define WV_S_BASE s_buf(bv, 0, s_base)
+#define WV_S_DST s_buf(bv, 0, s_dst)
+#define WV_S_MIRROR s_mirror
+            if (flags & CS_TWO) {
+#define WV_NS 2
+#include "mmc_wave_lat.inc"
+#undef WV_NS
+            } else {
+#define WV_NS 1
+#include "mmc_wave_lat.inc"
+#undef WV_NS
+            }
+#undef WV_S_MIRROR
+#undef WV_S_DST
+#undef WV_S_BASE
+        }
+        if (lane == 0)
+            ls.mvw[wv][0] = __longlong_as_double((long long)s_sum_out);
+        __syncthreads(); // every wave's sums are in ls.outw
+        if (wv == 0) {
+            lat_store_combined<true>(ls, out + g, lane, stamp);
+            if (wg_has_recip && (flags & CS_RECIP)) {
+                unsigned long long ss = 0;
+#pragma unroll
+                for (int q = 0; q < LAT_WAVES; q++)
+                    ss += (unsigned long long)__double_as_longlong(ls.mvw[q][0]);
+                const double word = lane == 0 ? __longlong_as_double((long long)ss) : 0.0;
+                const uint32_t csum = part_checksum_lanes(word, lane, stamp);
+                if (lane < 7)
+                    ls.comb[lane] = word;
+                if (lane == 7)
+                    ls.comb[7] = pack_ovl(0, 0, stamp, csum);
+                wave_sync();
+                store_part<true>(out + 8 + g, ls.comb, lane);
+                wave_sync();
+            }
+        }
     }
 }
