@@ -4,6 +4,7 @@
 #include "mmc_total.hpp"
 #include "mmc_wave.hpp"
 #include "mmc_lat.hpp"
+#include "mmc_potential.hpp"
 #include <string>
 #include <vector>
 
@@ -96,6 +97,12 @@ struct DeviceSystem {
     int32_t pair_totals_enqueue(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht, bool *fast);
     int32_t pair_totals_finish(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht, bool fast);
     int32_t totals_ewald(double lj_rcut, double qq_rcut, mmc_totals *tot /* [R] */);
+    // one system, one launch (mmc_potential.hpp): pair totals and / or structure factor + energy
+    TotalPart *d_tparts1 = nullptr; // [units] of the one-system launch
+    double *d_spart1 = nullptr;   // [POT_MAX_CHUNKS][2 * MMC_NK_STRIDE] chunk partials of S(k)
+    unsigned *d_ticket = nullptr; // the last-workgroup ticket, zero between launches
+    unsigned pot_stamp = 0;
+    int32_t potential_one(double lj_rcut, double qq_rcut, bool pairs, bool recip, PotOneOut *res);
     // sum_i 4 pot_i, sum_i 8 vir_i, sum_i EwaldReal_i and the overlap count, per replica
     int32_t pair_totals(double lj_rcut, double qq_rcut, std::vector<TotalsRaw> &ht);
     int32_t charge_sums(double *sum_q, double *sum_q2);

@@ -268,7 +268,7 @@ struct RecipOrder {
 };
 
 template <int M>
-__device__ __noinline__ void recip_column_lds(const int16_t *col, double *s0, double *s1, const double *ph,
+__device__ __forceinline__ void recip_column_lds(const int16_t *col, double *s0, double *s1, const double *ph,
                                              const double *qv, int n_atoms, int kx, int ky, int lane)
 {   // (plain pointers, not the BatchView: a struct passed by reference to a function that is not
     // inlined is copied to scratch by every thread)
@@ -296,22 +296,25 @@ __device__ __noinline__ void recip_column_lds(const int16_t *col, double *s0, do
             if (ky < 0)
                 ey = c_conj(ey);
         }
-        cplx ez[2 * M + 1]; // kz = -M .. M at index kz + M (ewalds.jl:575-585)
+        // kz = -M .. M at index kz + M: the powers of e^{i 2 pi z / L} by the reference's recurrence
+        // (ewalds.jl:575-585), each used as it is made -- the products are the ones an ez[] table
+        // would give, without holding the table in registers
         const cplx one = { 1.0, 0.0 };
-        ez[M] = one; ez[M + 1] = z1; ez[M - 1] = c_conj(z1);
-        cplx p = z1;
-#pragma unroll
-        for (int k = 2; k <= M; k++) {
-            p = c_mul(p, z1);
-            ez[M + k] = p;
-            ez[M - k] = c_conj(p);
-        }
         const cplx qxy = c_mul(c_rmul(q, ex), ey);
+        {
+            const cplx t = c_mul(qxy, one);
+            acc[2 * M] += t.re;
+            acc[2 * M + 1] += t.im;
+        }
+        cplx p = one;
 #pragma unroll
-        for (int k = 0; k < 2 * M + 1; k++) {
-            const cplx t = c_mul(qxy, ez[k]);
-            acc[2 * k] += t.re;
-            acc[2 * k + 1] += t.im;
+        for (int k = 1; k <= M; k++) {
+            p = k == 1 ? z1 : c_mul(p, z1);
+            const cplx tp = c_mul(qxy, p), tm = c_mul(qxy, c_conj(p));
+            acc[2 * (M + k)] += tp.re;
+            acc[2 * (M + k) + 1] += tp.im;
+            acc[2 * (M - k)] += tm.re;
+            acc[2 * (M - k) + 1] += tm.im;
         }
     }
     double tot[2 * (2 * M + 1)];
@@ -350,8 +353,10 @@ __global__ __launch_bounds__(RL_WAVES * 64) void k_recip_long_lds(BatchView bv, 
         qv[l] = bv.charge[l];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
+    const int lane0 = threadIdx.x & 63;
     for (;;) {
+        int lane = lane0;
+        asm volatile("" : "+v"(lane)); // keep lane-derived addresses of the inlined column bodies out of LICM
         int slot = 0;
         if (lane == 0)
             slot = atomicAdd(&next_col, 1);

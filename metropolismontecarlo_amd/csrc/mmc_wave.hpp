@@ -236,11 +236,19 @@ struct TotalWaveShared {
 };
 
 #define WV_TOTAL_WAVES_PER_SIMD 5 // 87 VGPRs: the single-state pair loop needs fewer than the move kernel
-__global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_total_wave(
-    BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
-    PairParams pp, TotalPart *out, int units_per_rep, int n_units, int paired)
-{
-    __shared__ __align__(16) TotalWaveShared sm;
+// The body: workgroup `wg` of `n_wgs` takes units wg * WV_WAVES + wave, + n_wgs * WV_WAVES, ...
+// (k_total_wave: the whole grid; k_potential_one: the pair workgroups of its grid).
+// COHERENT: the unit partials are written with device-scope stores (they bypass the non-coherent
+// part of the XCD's L2), for a reader in the SAME launch on another XCD (k_potential_one's last
+// workgroup) -- a release fence instead would write back the whole L2 once per workgroup.
+template <bool COHERENT>
+__device__ __forceinline__ void total_wave_body(
+    TotalWaveShared &sm, const BatchView &bv, const double *__restrict__ rec,
+    const double *__restrict__ qq_tab, const FastConsts &fc, const PairParams &pp, TotalPart *out,
+    int units_per_rep, int n_units, int paired, int wg, int n_wgs, int j_chunk = 0)
+{   // j_chunk > 0 (one system, latency): unit u = (molecule u / n_ch, chunk u % n_ch) scans only the
+    // j > i of molecules [chunk * j_chunk, (chunk + 1) * j_chunk) -- many short units instead of one
+    // wave walking a whole row; units_per_rep then counts those units
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += WV_WAVES * 64)
@@ -255,7 +263,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
     const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
     int32_t *const list = sm.list[wv];
 
-    for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
+    for (int unit = wg * WV_WAVES + wv; unit < n_units; unit += n_wgs * WV_WAVES) {
         int lane = lane0;
         asm volatile("" : "+v"(lane)); // see k_move_eval_wave
         const int r = unit / units_per_rep, u = unit - r * units_per_rep;
@@ -272,7 +280,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
         // of its neighbours above it, molecule n_mol - 1 - u nearly none).
         // (paired == 0: one molecule per unit -- twice the waves with uneven work, for the latency
         // of a single system's evaluation)
-        const int iA = u, iB = n_mol - 1 - u;
+        const int n_ch = j_chunk > 0 ? (n_mol + j_chunk - 1) / j_chunk : 1;
+        const int j_lo = j_chunk > 0 ? (u % n_ch) * j_chunk : 0;
+        const int j_hi = j_chunk > 0 ? min(j_lo + j_chunk, n_mol) : n_mol;
+        const int iA = j_chunk > 0 ? u / n_ch : u, iB = n_mol - 1 - u;
         const bool hasB = paired && iB > iA; // the middle molecule of an odd count stands alone
         double wA = 0.0, wB = 0.0;
         if (lane < MMC_REC) {
@@ -367,14 +378,14 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
             // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1, WV_TPF of
             // them per trip with no branch around a load (see mmc_wave_unit.inc); blocks past the
             // last molecule test clamped, masked lanes
-            int base = (i0 + 1) & ~63;
+            int base = max(i0 + 1, j_lo) & ~63;
             uint32_t fxy[WV_TPF], fz[WV_TPF];
 #pragma unroll
             for (int b = 0; b < WV_TPF; b++) {
                 const int j = min(base + 64 * b + lane, n_mol - 1);
                 fxy[b] = sxy[j]; fz[b] = sz[j];
             }
-            while (base < n_mol) {
+            while (base < j_hi) {
 #pragma unroll
                 for (int b = 0; b < WV_TPF; b++) {
                     const int j = base + lane;
@@ -383,8 +394,8 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
                         const int jn = min(base + 64 * WV_TPF + lane, n_mol - 1);
                         fxy[b] = sxy[jn]; fz[b] = sz[jn];
                     }
-                    const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q) && (j < n_mol)
-                                      && (j > i0);
+                    const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q) && (j < j_hi)
+                                      && (j > i0) && (j >= j_lo);
                     const unsigned long long m = wave_ballot(keep);
                     if (keep)
                         list[cnt + lanes_below(m)] = j | (half << 27);
@@ -406,9 +417,27 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_tota
             o.lj_pot = s0; o.lj_vir = s1; o.qq = s2;
             o.n_ovl = any_ovl ? 1 : 0;
             o._pad = 0;
-            out[unit] = o;
+            if (COHERENT) {
+                double *w = reinterpret_cast<double *>(out + unit);
+                __hip_atomic_store(w, o.lj_pot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w + 1, o.lj_vir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(w + 2, o.qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(reinterpret_cast<long long *>(w + 3), (long long)o.n_ovl,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                out[unit] = o;
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_total_wave(
+    BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
+    PairParams pp, TotalPart *out, int units_per_rep, int n_units, int paired)
+{
+    __shared__ __align__(16) TotalWaveShared sm;
+    total_wave_body<false>(sm, bv, rec, qq_tab, fc, pp, out, units_per_rep, n_units, paired,
+                           (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Per replica: the unit partials added in index order by one workgroup (fixed order: bitwise

@@ -1,5 +1,5 @@
 import sys, os, time
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, "tests")
 import numpy as np
 import common
 from metropolismontecarlo_amd import structs, io as mio

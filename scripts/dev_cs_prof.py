@@ -1,6 +1,6 @@
 """Developer timing of the context server's phases (build with -DCS_PROFILE, MMC_HIP_LIB=...)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from metropolismontecarlo_amd import io as mio, structs
 from metropolismontecarlo_amd.device import Context

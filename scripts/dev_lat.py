@@ -1,6 +1,6 @@
 """Developer timing of the move server shapes: us per step of R chains (750 molecules)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from metropolismontecarlo_amd import io as mio, structs
 from metropolismontecarlo_amd.device import Batch
