@@ -91,6 +91,16 @@ int32_t mmc_download_system(mmc_ctx *ctx, double *com, double *coords);
  * sumQExp arrays.  Follow with mmc_potential_ewald for the energy at the new volume
  * (volumeChange.jl:91-111). */
 int32_t mmc_volume_change(mmc_ctx *ctx, double new_box, double new_kappa);
+/* One NPT volume move without a host round trip (Ewald/volumeChange.jl:59-147, `MC_vol`).
+ * mmc_volume_trial: copies aside ON THE DEVICE everything the move rewrites (coordinates in their
+ * three layouts, fixed-point centres of mass, S(k), k-vectors, erfc table; one launch), then does
+ * mmc_volume_change + mmc_potential_ewald: `tot` is the energy at the new volume (:91-111).
+ * mmc_volume_accept (:132-147): nothing left to do.  mmc_volume_reject: the copy back (one
+ * launch): coordinates, tables and S(k) are the pre-move ones bit for bit. */
+int32_t mmc_volume_trial(mmc_ctx *ctx, double new_box, double new_kappa, double lj_rcut,
+                         double qq_rcut, mmc_totals *tot);
+int32_t mmc_volume_accept(mmc_ctx *ctx);
+int32_t mmc_volume_reject(mmc_ctx *ctx);
 
 /* PrepareEwaldVariables(ewald, boxSize)                       Ewald/ewalds.jl:45-103
  * Builds kxyz/cfac on the device, zeroes sumQExpOld/New.  k_sq_max != 27 -> MMC_ERR_ASSERT (:49).
@@ -274,7 +284,11 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *   "kernel"           2 = one wavefront per trial move, persistent workgroups, erfc(kappa r)/r
  *                      table; 1 = one workgroup per trial move (LDS-tiled, same table);
  *                      3 = 2 for launches of at least 16 moves per compute unit, else 1 (default
- *                      when every molecule has the same atom types and charges); 0 = generic
+ *                      when every molecule has the same atom types and charges); 0 = generic;
+ *                      4 = the latency form (k_move_eval_lat): "parts" (4, 8, 12 or 16) are waves,
+ *                      four to a workgroup, each pair part's molecules resident in the wave, three
+ *                      lanes to a neighbour, the reciprocal sum split over 1..3 waves; the form the
+ *                      move server takes for few replicas -- same chains bit for bit as that server
  *   "wave_wgs"         workgroups of a kernel-2 launch (0 = 4 per compute unit)
  *   "inject_torn"      N > 0: the native driver corrupts its first N copies of result records
  *                      before checking them, as a torn PCIe write would (test hook: the check must
@@ -298,6 +312,13 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      a host that stops talking gets MMC_ERR_HIP from the run, not a hung GPU.
  *                      -1 (default) = use it for up to 128 replicas when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
+ *   "trace_steps"      test hook: see mmc_batch_get_trace
+ *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 up to 4 replicas,
+ *                      else 2, when every workgroup's molecule ranges fit its waves' resident
+ *                      storage (at most 128 molecules per pair part) and R x workgroups does not
+ *                      exceed the compute units; 0 = one workgroup per replica (k_move_server_wave);
+ *                      2..4 = that many (k_move_server_lat: each workgroup polls the replica's
+ *                      control word itself and keeps its own copy of its molecules)
  *   "server_stall_ms"  test hook: the driver sleeps this long before posting the control words of
  *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP) */
 int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
@@ -333,6 +354,10 @@ int32_t mmc_part_validate(const void *part_out_64, uint32_t stamp);
 /* Copy the raw 64-byte result record of (replica r, part) of the last mmc_batch_eval and the
  * stamp of that launch (test hook for the hand-off check). */
 int32_t mmc_batch_peek_part(mmc_batch *b, int64_t r, int32_t part, void *out64, uint32_t *stamp);
+/* Test hook: with option "trace_steps" = N the native driver records, for the first N steps of a
+ * run and every replica, dU = d_lj + d_real + d_recip (main.jl:593) and the decision -- bit 0
+ * accepted, bit 1 overlap, bit 2 the move was a rotation.  delta, flags: [R][N]. */
+int32_t mmc_batch_get_trace(mmc_batch *b, double *delta, uint8_t *flags);
 /* Settle the last outstanding proposals without evaluating new ones. */
 int32_t mmc_batch_settle(mmc_batch *b, const int32_t *accept);
 

@@ -100,6 +100,9 @@ SIGNATURES = {
     "mmc_download_system": [_vp, _dp, _dp],
     "mmc_volume_change": [_vp, _d, _d],
     "mmc_batch_volume_change": [_vp, _d, _d],
+    "mmc_volume_trial": [_vp, _d, _d, _d, _d, C.POINTER(Totals)],
+    "mmc_volume_accept": [_vp],
+    "mmc_volume_reject": [_vp],
     "mmc_prepare_ewald": [_vp, _d, _i64, _i64, _d, _d, _i64p],
     "mmc_get_kvectors": [_vp, _i32p, _dp],
     "mmc_get_sumqexp": [_vp, _dp, _dp],
@@ -137,6 +140,7 @@ SIGNATURES = {
     "mmc_batch_set_option": [_vp, C.c_char_p, _i64],
     "mmc_batch_qq_table": [_vp, _dp, _i64, _dp],
     "mmc_batch_settle": [_vp, _i32p],
+    "mmc_batch_get_trace": [_vp, _dp, C.POINTER(C.c_uint8)],
     "mmc_batch_set_orientations": [_vp, _dp, _dp, _i32],
     "mmc_batch_get_orientations": [_vp, _i64, _dp],
     "mmc_part_validate": [_vp, C.c_uint32],

@@ -108,6 +108,19 @@ struct DeviceSystem {
     int32_t charge_sums(double *sum_q, double *sum_q2);
     // volume move: rescale every replica to `new_box` and rebuild the Ewald tables (K6)
     int32_t volume_change(double new_box, double new_kappa);
+    // everything a volume move rewrites, kept on the device so that a rejection is a copy back
+    // (one launch) and an acceptance is nothing: coordinates in their three layouts, the
+    // fixed-point centres of mass, S(k), the Ewald tables; and the scalars that go with them
+    struct {
+        bool valid = false;
+        uint32_t *buf = nullptr; // one allocation, the segments back to back
+        SnapSegs to_snap{}, from_snap{};
+        double box = 0, kappa = 0;
+        int64_t nkvecs = 0;
+        RecipOrder recip_order{};
+    } snap;
+    int32_t snapshot_take();
+    int32_t snapshot_restore();
 };
 
 PairParams mmc_pair_params(double lj_rcut, double qq_rcut, double diameter, double ovr,

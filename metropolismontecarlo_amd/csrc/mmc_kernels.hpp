@@ -634,6 +634,23 @@ __global__ void k_copy_s(BatchView bv, int dst, int src)
         s_buf(bv, 0, dst)[k] = s_buf(bv, 0, src)[k];
 }
 
+// Copy up to 12 device arrays in one launch (the snapshot a volume move takes of everything it
+// rewrites, and its restoration on rejection): segment q holds n[q] 32-bit words.
+#define MMC_SNAP_SEGS 12
+struct SnapSegs {
+    uint32_t *dst[MMC_SNAP_SEGS];
+    const uint32_t *src[MMC_SNAP_SEGS];
+    int64_t n[MMC_SNAP_SEGS];
+    int count;
+};
+__global__ void k_copy_segments(SnapSegs g)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int q = 0; q < g.count; q++)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < g.n[q]; i += stride)
+            g.dst[q][i] = g.src[q][i];
+}
+
 // AoS (Julia Vector{SVector{3,Float64}}) -> SoA for one replica; n elements.
 __global__ void k_aos_to_soa(const double *aos, double *x, double *y, double *z, int n)
 {

@@ -125,6 +125,23 @@ class Context:
         check(self._L.mmc_volume_change(self._h, float(new_box), float(new_kappa)))
         self.box = float(new_box)
 
+    def volume_trial(self, new_box, new_kappa, lj_rcut, qq_rcut):
+        """mmc_volume_trial: snapshot on the device, rescale, new tables, total energy at the new
+        volume.  Follow with volume_accept() or volume_reject()."""
+        t = Totals()
+        check(self._L.mmc_volume_trial(self._h, float(new_box), float(new_kappa), float(lj_rcut),
+                                       float(qq_rcut), C.byref(t)))
+        self._box_before_trial = self.box
+        self.box = float(new_box)
+        return t.asdict()
+
+    def volume_accept(self):
+        check(self._L.mmc_volume_accept(self._h))
+
+    def volume_reject(self):
+        check(self._L.mmc_volume_reject(self._h))
+        self.box = self._box_before_trial
+
     # -- a6 ------------------------------------------------------------------------------------
     def prepare_ewald(self, kappa, nk, k_sq_max, box, factor):
         n = C.c_int64()
@@ -377,6 +394,14 @@ class Batch:
         e = np.zeros(self.R) if energies is None else _f64(energies).copy()
         check(self._L.mmc_batch_run(self._h, C.byref(p), _d(e), C.byref(st)))
         return e, st.asdict()
+
+    def get_trace(self, n_steps):
+        """(dU[R, n], flags[R, n]) of the first n steps of the last run (option "trace_steps" = n):
+        flags bit 0 accepted, bit 1 overlap, bit 2 rotation."""
+        d = np.zeros((self.R, int(n_steps)))
+        f = np.zeros((self.R, int(n_steps)), dtype=np.uint8)
+        check(self._L.mmc_batch_get_trace(self._h, _d(d), f.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return d, f
 
     def set_orientations(self, quat, db, faithful=True):
         """Turn on the reference's quaternion move generation for device-side proposals

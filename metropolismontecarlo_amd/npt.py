@@ -24,9 +24,10 @@ def VolumeChange(ctx, energy_old, box, n_mol, pressure, temperature, vmax, lj_rc
                  alpha=5.6):
     """One volume move of the system held by `ctx` (device.Context).
 
-    Returns (accepted, box, energy, totals).  On rejection the previous coordinates and tables are
-    restored exactly (from a host copy taken before the move), as `MC_vol` only overwrites its
-    state when the move is accepted (volumeChange.jl:132-147)."""
+    Returns (accepted, box, energy, totals).  On rejection the previous coordinates, tables and
+    S(k) are restored exactly -- from a copy the DEVICE took before the move (mmc_volume_trial /
+    mmc_volume_reject: one launch each way, nothing crosses PCIe) -- as `MC_vol` only overwrites
+    its state when the move is accepted (volumeChange.jl:132-147); acceptance costs nothing."""
     vol_old = box ** 3
     vol_new = vol_old + (rng.random() - 0.5) * vmax
     if vol_new <= 0.0:
@@ -34,19 +35,16 @@ def VolumeChange(ctx, energy_old, box, n_mol, pressure, temperature, vmax, lj_rc
     L_new = vol_new ** (1.0 / 3.0)
     if lj_rcut > L_new / 2 or qq_rcut > L_new / 2:
         return False, box, energy_old, None        # minimum image would break: reject outright
-    saved = ctx.download_system()
-    ctx.volume_change(L_new, alpha / L_new)
-    tot = ctx.potential_ewald(lj_rcut, qq_rcut)
+    tot = ctx.volume_trial(L_new, alpha / L_new, lj_rcut, qq_rcut)
     energy_new = tot["energy"]
     beta = 1.0 / temperature
     arg = -beta * (pressure * (vol_new - vol_old) - n_mol * math.log(vol_new / vol_old) / beta
                    + (energy_new - energy_old))
     test = math.exp(min(arg, 700.0))
     if rng.random() < test:
+        ctx.volume_accept()
         return True, L_new, energy_new, tot
-    ctx.volume_change(box, alpha / box)            # tables of the old box ...
-    ctx.update_system(*saved)                      # ... and the exact old coordinates
-    ctx.recip_long()                               # S(k) of the restored configuration
+    ctx.volume_reject()
     return False, box, energy_old, None
 
 

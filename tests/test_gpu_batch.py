@@ -572,6 +572,27 @@ def test_fast_kernel_with_several_lj_pairs_per_molecule_pair(orc):
             b.settle(acc_prev)
 
 
+@pytest.mark.parametrize("n_mol,R", [(101, 96), (751, 12), (75, 128)])
+def test_half_pair_totals_with_an_odd_molecule_count(n_mol, R, orc):
+    """k_total_wave in its PAIRED mode (a wave takes molecules u and N-1-u; chosen when the batch
+    has at least 4096 such units) with an odd number of molecules: the middle molecule stands
+    alone (`hasB = paired && iB > iA`).  All terms against the oracle, every replica the same."""
+    a = _dense_water(n_mol, seed=3)
+    assert (n_mol + 1) // 2 * R >= 4096 and n_mol % 2 == 1
+    rcut = min(RCUT, a["box"] / 2)
+    from metropolismontecarlo_amd import structs
+    from metropolismontecarlo_amd.device import Batch
+    with Batch(R, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+               5.6 / a["box"], structs.factor, rcut, rcut) as b:
+        t = b.potential_ewald(as_array=True)
+    s = common.oracle_system(a)
+    to = orc.potential_ewald(s, orc.Ewald(5.6 / s.box, 5, 27, s.box), rcut, rcut)
+    for key in ("energy", "virial", "lj", "real", "recip", "self"):
+        assert rel(t[key][0], to[key], 1.0) < TOL, key
+        assert np.array_equal(t[key], np.full(R, t[key][0])), key
+    assert t["n_overlap"][0] == to["n_overlap"]
+
+
 def test_potential_ewald_record_array_equals_dict_list():
     a = common.nist_arrays(1, "unwrapped")
     with make_batch(a, 3) as b:
@@ -617,6 +638,85 @@ def test_bench_path_750_molecules_device_moves(kernel, orc):
                 assert rel(t1[key][r], to[key]) < TOL, (r, key)
             assert (com >= 0).all() and (com <= a["box"]).all()
             assert np.abs(com - a["com"]).max() > 0.05          # it moved
+
+
+def _rigid_proposal(seed, replica, step, com, atoms, box, dr_max, dphi_max):
+    """The move k_propose's rigid generator makes for (seed, replica, step) of a molecule at
+    com / atoms, rebuilt on the host from the exported Philox draws with the reference's
+    formulas (see test_gpu_moves.py).  Returns (kind, com_new, atoms_new, metropolis uniform)."""
+    import math
+    from metropolismontecarlo_amd import moves
+    from test_gpu_moves import ReferenceOrder, SLOT_METROPOLIS, philox_pair
+    draws = ReferenceOrder(seed, replica, step)
+    u_met = philox_pair(seed, replica, step, SLOT_METROPOLIS)[0]
+    if draws.chose_move() < 0.5:                                           # main.jl:519
+        draws.start_translation()
+        c_new = moves.random_translate_vector(dr_max, com, box, draws)
+        return 0, c_new, atoms + (c_new - com), u_met
+    draws.start_rotation()
+    axis = moves.random_vector(draws)
+    angle = (2.0 * draws.random() - 1.0) * dphi_max
+    c, sn = math.cos(angle), math.sin(angle)
+    t = 1.0 - c
+    ex, ey, ez = axis
+    Rm = np.array([[t * ex * ex + c, t * ex * ey - sn * ez, t * ex * ez + sn * ey],
+                   [t * ex * ey + sn * ez, t * ey * ey + c, t * ey * ez - sn * ex],
+                   [t * ex * ez - sn * ey, t * ey * ez + sn * ex, t * ez * ez + c]])
+    return 1, com.copy(), com + (atoms - com) @ Rm.T, u_met
+
+
+@pytest.mark.parametrize("kernel,R,parts", [(2, 24, 1), (1, 2, 0), (4, 1, 16)])
+def test_driver_device_moves_stepped_by_the_oracle(kernel, R, parts, orc):
+    """mmc_batch_run with device-side proposals at 750 molecules, every step checked: the oracle
+    steps the same chains -- proposal rebuilt from the exported Philox draws, dU from
+    orc.trial_move, Metropolis (auxillary.jl:106-114) with the step's own uniform -- and the
+    driver's recorded dU and decision of EVERY step (option "trace_steps"), accepted or
+    rejected, must agree: a wrong dU on a rejected move cannot hide in the final state."""
+    import math
+    a = common.nist_arrays(4, "unwrapped")
+    n_mol, box = a["com"].shape[0], a["box"]
+    n_steps, seed, T, dr, dphi = 90, 424242, 298.15, 0.316555789, 0.05
+    check = (0, R - 1) if R > 1 else (0,)
+    with make_batch(a, R) as b:
+        b.set_option("kernel", kernel)
+        b.set_option("device_moves", 1)
+        b.set_option("persistent", 0 if kernel != 4 else 1)   # launch per step; the latency server
+        b.set_option("trace_steps", n_steps)
+        e0 = b.potential_ewald(as_array=True)["energy"].copy()
+        e1, st = b.run(n_steps, T, dr, dphi, seed=seed, energies=e0, n_groups=min(R, 2),
+                       n_parts=parts, n_threads=2, replica0=5)
+        d_gpu, f_gpu = b.get_trace(n_steps)
+        final = {r: b.get_replica(r) for r in check}
+    n_rej = n_rot = 0
+    for r in check:
+        s = common.oracle_system(a)
+        ew = orc.Ewald(5.6 / box, 5, 27, box)
+        orc.recip_long(ew, s.coords, s.charge, box)
+        running = 0.0
+        for step in range(n_steps):
+            i = step % n_mol                                              # main.jl:490
+            kind, c_new, a_new, u = _rigid_proposal(seed, 5 + r, step, s.com[i].copy(),
+                                                    s.coords[3 * i:3 * i + 3].copy(), box, dr, dphi)
+            d, ov = orc.trial_move(i + 1, s, ew, RCUT, RCUT, c_new, a_new)
+            delta = d[0] + d[1] + d[2]                                    # main.jl:593
+            x = delta / T
+            accept = (x < 0.0 or math.exp(-x) > u) and not ov             # main.jl:598
+            assert abs(d_gpu[r, step] - delta) < TOL * (abs(delta) + 1e4), (r, step, kind)
+            assert f_gpu[r, step] == (int(accept) | (int(ov) << 1) | (kind << 2)), (r, step)
+            n_rej += not accept
+            n_rot += kind
+            if accept:
+                running += delta
+                s.com[i] = c_new
+                s.coords[3 * i:3 * i + 3] = a_new
+                ew.sumQExpOld = ew.sumQExpNew.copy()
+            else:
+                ew.sumQExpNew = ew.sumQExpOld.copy()
+        com, coords, S = final[r]
+        assert np.abs(com - s.com).max() < 2e-13 and np.abs(coords - s.coords).max() < 2e-13
+        assert np.abs(S - ew.sumQExpOld).max() < 1e-11 * np.abs(ew.sumQExpOld).max()
+        assert abs((e1[r] - e0[r]) - running) < TOL * 1e5
+    assert n_rej > 5 and n_rot > 10          # rejected moves and rotations were among the checked
 
 
 def _dense_water(n_mol, seed=5):
