@@ -320,7 +320,13 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      2..4 = that many (k_move_server_lat: each workgroup polls the replica's
  *                      control word itself and keeps its own copy of its molecules)
  *   "server_stall_ms"  test hook: the driver sleeps this long before posting the control words of
- *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP) */
+ *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP)
+ *   "server_seq_offset" test hook: the control words' sequence numbers (24 bits, compared modulo
+ *                      2^24 on both sides) start at this offset instead of 0
+ * A run that fails half-way (a server that timed out, a HIP error) leaves accepted moves, S-buffer
+ * parity and the caller's energies in doubt: the batch then returns MMC_ERR_STATE from
+ * mmc_batch_run / run_chains / eval until EVERY replica has been set again
+ * (mmc_batch_set_replica); recompute the energies (mmc_batch_potential_ewald) after that. */
 int32_t mmc_batch_set_option(mmc_batch *b, const char *key, int64_t value);
 /* The fast kernel's approximation of erfc(kappa r)/r (ewalds.jl:367) evaluated at n values of
  * r^2 in (0, 256): lets a test bound its error against an exact evaluation. */
@@ -381,8 +387,14 @@ typedef struct {
                             host proposals, one for all with "device_moves") */
     int32_t _pad;
     uint64_t replica0;   /* global index of this batch's replica 0 (a rank that owns chains
-                            [g0, g0 + R) of a larger ensemble passes g0): trajectories depend on
-                            (seed, global index) only, not on how chains are spread over GPUs */
+                            [g0, g0 + R) of a larger ensemble passes g0): the RANDOM DRAWS of a
+                            chain depend on (seed, global index) only.  Its energies also depend,
+                            in the last bits, on the order its dU terms are summed in, which the
+                            batch picks from its own size (kernel by launch size, parts per move,
+                            move server up to 128 replicas): shardings that use the same
+                            "kernel", n_parts and "persistent" / "server_wgs" on every rank
+                            reproduce one another bit for bit; others agree to ~1e-13 per move
+                            and may part ways at a Metropolis comparison eventually */
 } mmc_run_params;
 
 /* Random streams.  Device-side proposals ("device_moves"): every draw is Philox4x32-10 with key =

@@ -60,6 +60,8 @@ struct DeviceSystem {
     double *d_spart = nullptr;     // [R][16][2 * MMC_NK_STRIDE] chunk partials of S(k), lazily
     bool sums_valid = false;       // c_sq / c_sq2 = sum q, sum q^2 of the uploaded charges
     bool recip_lds_ready = false;  // k_recip_long_lds has been granted its dynamic LDS size
+    int64_t lds_per_block = 0;     // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (init)
+    bool recip_lds_refused = false; // the device would not grant the LDS k_recip_long_lds asks for
     RecipOrder recip_order;        // its (kx, ky) columns, most work first (prepare_ewald)
     double c_sq = 0.0, c_sq2 = 0.0;
     bool fast_table_ok(double qq_rcut) const; // the erfc table covers this cutoff

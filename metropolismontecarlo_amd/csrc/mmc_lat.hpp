@@ -306,7 +306,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
                     v = __hip_atomic_load(sa.ctrl + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32)
                     | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-                if ((c >> 40) == ((unsigned long long)(step + 1) & 0xffffffULL) || (c & SRV_QUIT))
+                if ((c >> 40) == (((unsigned long long)(step + 1) + sa.seq_off) & 0xffffffULL) || (c & SRV_QUIT))
                     break;
                 if ((spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > SRV_TIMEOUT_TICKS) {
                     if (lane == 0) {

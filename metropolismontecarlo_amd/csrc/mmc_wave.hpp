@@ -495,6 +495,8 @@ struct ServerArgs {
     uint64_t seed, replica0;
     int64_t rng_off;
     int32_t *timeout_flag;          // pinned host: [0] raised, [1..4] who waited for what
+    uint64_t seq_off;               // added to the step's sequence number on both sides (test hook:
+                                    // start a run just below the 2^24 wrap of the control word)
 };
 #define SRV_ACCEPT 1u
 #define SRV_SCUR 2u
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
                 c = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32)
                     | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
                 // (the word carries the sequence number modulo 2^24: compare modulo 2^24)
-                if ((c >> 40) == ((unsigned long long)(step + 1) & 0xffffffULL) || (c & SRV_QUIT))
+                if ((c >> 40) == (((unsigned long long)(step + 1) + sa.seq_off) & 0xffffffULL) || (c & SRV_QUIT))
                     break; // (a host that gives up early posts "quit" with whatever sequence number)
                 if ((spins & 63) == 0 && __builtin_amdgcn_s_memrealtime() - t0 > SRV_TIMEOUT_TICKS) {
                     if (lane == 0) { // what this workgroup was waiting for, for the host's message

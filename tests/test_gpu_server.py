@@ -145,6 +145,24 @@ def test_server_default_is_automatic_and_uses_fewer_launches():
     assert np.array_equal(res[0][0], res[1][0]) and same(res[0][1], res[1][1])
 
 
+@pytest.mark.parametrize("kernel,parts,wgs", [(2, 3, 0), (4, 8, -1)])
+def test_server_sequence_numbers_wrap(kernel, parts, wgs):
+    """The control word carries the step's sequence number in 24 bits.  A run that crosses 2^24
+    (started 60 steps below it through the test hook; a single chain gets there after ~3 minutes)
+    must go on, with both forms of the server, and sample the chain of the launch-per-step driver."""
+    a = common.nist_arrays(1, "unwrapped")
+    res = []
+    for persistent in (1, 0):
+        with make_batch(a, 2, persistent, kernel=kernel) as b:
+            b.set_option("server_wgs", wgs)
+            b.set_option("server_seq_offset", (1 << 24) - 60)
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            e, st = b.run(200, 298.15, 0.316555789, 0.05, 9, e, n_groups=1, n_parts=parts)
+            assert st["server_steps"] == (200 if persistent else 0) and st["moves"] == 400
+            res.append((e, state(b)))
+    assert np.array_equal(res[0][0], res[1][0]) and same(res[0][1], res[1][1])
+
+
 def test_server_refuses_what_it_cannot_do():
     a = common.nist_arrays(1, "unwrapped")
     with make_batch(a, 1, 1, kernel=0) as b:      # the generic kernel has no server form
@@ -170,6 +188,13 @@ def test_server_wait_is_bounded():
         with pytest.raises(MMCError, match="timed out waiting for a control word"):
             b.run(10, 298.15, 0.3, 0.05, 3, e, n_groups=1)
         b.set_option("server_stall_ms", 0)
+        # accepted moves, S-buffer parity and `e` may disagree now: the batch says so until every
+        # replica has been loaded again
+        with pytest.raises(MMCError, match="MMC_ERR_STATE"):
+            b.run(10, 298.15, 0.3, 0.05, 3, e, n_groups=1)
+        b.set_replica(0, a["com"], a["coords"])
+        with pytest.raises(MMCError, match="MMC_ERR_STATE"):
+            b.run(10, 298.15, 0.3, 0.05, 3, e, n_groups=1)
         for r in range(2):
             b.set_replica(r, a["com"], a["coords"])
         e0 = b.potential_ewald(as_array=True)["energy"].copy()
