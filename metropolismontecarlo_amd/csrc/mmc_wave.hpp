@@ -272,7 +272,7 @@ __device__ __forceinline__ void total_wave_body(
         const uint32_t *sxy = reinterpret_cast<const uint32_t *>(cq0);
         const uint16_t *sz = cq0 + 2 * bv.cq_stride;
         double a_lj = 0, a_v = 0, a_q = 0;
-        bool ovl = false; // per-lane overlap flag (a lane mask in SGPRs), one ballot per unit
+        unsigned long long ovm = 0; // lanes that saw an overlap
 
         // The unit's two molecules as lane-distributed records (lane t = word t); the neighbours
         // of both go into ONE list, tagged with the molecule they belong to, so that the pair
@@ -320,6 +320,7 @@ __device__ __forceinline__ void total_wave_body(
                 const double c0 = x0 * x0 + y0 * y0 + z0 * z0;
                 const bool g0 = act && (c0 < pp.qq_gate_sq);
                 const bool l0 = same_gate ? g0 : (act && (c0 < pp.lj_gate_sq));
+                const unsigned long long gm0 = wave_ballot(g0);
                 auto pair_ab = [&](int ab, double ax, double ay, double az, double bx, double by,
                                    double bz) {
                     const double qq = fc.qq9[ab];
@@ -327,14 +328,17 @@ __device__ __forceinline__ void total_wave_body(
                     const double px = vector1D_abs(ax, bx, bc), py = vector1D_abs(ay, by, bc),
                                  pz = vector1D_abs(az, bz, bc);
                     const double u0 = px * px + py * py + pz * pz;
-                    const bool ov0 = g0 && qneg && (u0 < pp.ovr);          // ewalds.jl:359
-                    const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq);  // ewalds.jl:362
+                    const bool c0 = u0 < pp.ovr;
+                    const unsigned long long cm0 = wave_ballot(c0) & gm0; // scalar mask arithmetic, see
+                    const bool ov0 = g0 && qneg && c0;                    // mmc_wave_unit.inc (ewalds.jl:359)
+                    const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq); // ewalds.jl:362
                     double e0 = qq_table_eval_clamped(sm.qtab, u0);
-                    if (wave_any(in0 && (u0 < pp.ovr))) {
+                    if (qneg) {
+                        ovm |= cm0;
+                    } else if (cm0 != 0ULL) {
                         if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
                     }
                     a_q = fma(e0, in0 ? qq : 0.0, a_q);
-                    ovl = ovl || ov0;
                     const double eps = fc.eps9[ab], sg = fc.sig9[ab];
                     if (eps > 0.001) { // uniform (energy.jl:270)
                         if (l0 && u0 < pp.lj_slack_sq) {
@@ -410,8 +414,8 @@ __device__ __forceinline__ void total_wave_body(
         }
         if (cnt)
             process(cnt);
-        const double s0 = wave_sum(a_lj), s1 = wave_sum(a_v), s2 = wave_sum(a_q);
-        const bool any_ovl = wave_any(ovl); // (all lanes: a ballot)
+        const double s0 = wave_sum_rows(a_lj), s1 = wave_sum_rows(a_v), s2 = wave_sum_rows(a_q);
+        const bool any_ovl = ovm != 0ULL;
         if (lane == 0) {
             TotalPart o;
             o.lj_pot = s0; o.lj_vir = s1; o.qq = s2;
