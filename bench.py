@@ -100,6 +100,26 @@ def pmc_traffic(kernel, moves_per_launch):
                                    "command (committed); not measured in this run")
 
 
+def pmc_extras(kernel, moves_per_launch):
+    """What the committed rocprofv3 PMC passes of this command say beyond bytes (profiles/
+    *_default_pmc_summary.json, written by scripts/summarize_profile.py): VALU instructions per
+    move, the share of cycles the vector pipe issues, the clock.  Only for the kernel and launch
+    shape they were collected for; not measured in this run."""
+    try:
+        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
+                      if p.endswith("_default_pmc_summary.json"))[-1]
+        t = json.load(open(os.path.join(ROOT, "profiles", path)))
+        ex = t["roofline_extras"]
+    except (IndexError, OSError, ValueError, KeyError):
+        return {}
+    if ex.get("kernel") != kernel or int(ex.get("moves_per_launch", -1)) != int(moves_per_launch):
+        return {}
+    out = {k: ex[k] for k in ("valu_insts_per_move", "valu_busy_frac", "clock_ghz", "hbm_traffic_gbs",
+                              "hbm_traffic_frac", "waves_per_simd") if k in ex}
+    out["counters_source"] = f"profiles/{path} (rocprofv3 --pmc passes of this command; not measured in this run)"
+    return out
+
+
 def cpu_baseline(a, budget_s, n_threads=1):
     """Time the oracle (C port of the reference path) on the same workload: Loop()'s hot-path
     calls for successive molecules with small rigid translations, in a C loop
@@ -130,6 +150,21 @@ def kernel_name(kernel_opt, moves_per_launch, parts):
     if kernel_opt in (1, 2):
         return {1: "k_move_eval_fast", 2: "k_move_eval_wave"}[kernel_opt]
     return "k_move_eval_wave" if moves_per_launch * parts >= 16 * N_CUS else "k_move_eval_fast"
+
+
+def server_lat_parts(R, n_mol):
+    """Parts (waves) of the latency move server the library takes for R replicas (batch_lat_shape,
+    csrc/mmc_batch.inc), or 0 when it takes the one-workgroup server or none."""
+    if R > 128:
+        return 0
+    G = 4 if R <= 4 else 2
+    while G >= 2:
+        P = 4 * G
+        nr = 3 if P >= 12 else 2
+        if -(-n_mol // (P - nr)) <= 128:
+            return P
+        G -= 1
+    return 0
 
 
 def shape_for(R, args):
@@ -205,10 +240,21 @@ def launch_mode_roofline(R, a, args, local_rank, g0, barrier, shape, n_mol, box,
     """The move server has no launches to time: the roofline object of a small batch comes from a
     second, short run of the same batch with a launch per step (persistent = 0)."""
     sh = dict(shape, steps=min(shape["steps"], 600), warmup=min(shape["warmup"], 60))
-    r_ = measure_moves(R, a, args, local_rank, g0, barrier, sh, persistent=0)
-    rf = roofline_object(r_, R, args, sh, n_mol, box, parts_used)
+    lat_parts = server_lat_parts(R, n_mol)
+    if lat_parts and args.kernel == 3:
+        # the server ran k_move_server_lat: its launch-per-step form is k_move_eval_lat with the
+        # same parts (same arithmetic, bit-identical chains -- tests/test_gpu_server.py)
+        a2 = argparse.Namespace(**{**vars(args), "kernel": 4})
+        r_ = measure_moves(R, a, a2, local_rank, g0, barrier, sh, n_parts=lat_parts, persistent=0)
+        rf = roofline_object(r_, R, a2, sh, n_mol, box, lat_parts // 4)
+        if rf:
+            rf["kernel"] = "k_move_eval_lat"
+    else:
+        r_ = measure_moves(R, a, args, local_rank, g0, barrier, sh, persistent=0)
+        rf = roofline_object(r_, R, args, sh, n_mol, box, parts_used)
     if rf:
-        rf["measured_in"] = "a separate run with a launch per step (persistent = 0)"
+        rf["measured_in"] = ("a separate run with a launch per step (persistent = 0) of the kernel "
+                             "the move server is the persistent form of")
         rf["us_per_step_launch_per_step"] = 1e6 * r_["elapsed"] / sh["steps"]
     return rf
 
@@ -224,8 +270,12 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
     name = kernel_name(args.kernel, moves_per_launch, parts_used)
     traffic, source = pmc_traffic(name, moves_per_launch)
     return {
+        **pmc_extras(name, moves_per_launch),
         "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
+        "what_binds": "frac is ALGORITHMIC bytes (SURVEY 8d) over time; the kernel moves half of "
+                      "them (traffic) and is bound by fp64 VALU issue (valu_busy_frac) together with "
+                      "latency -- see DESIGN.md section 4",
         "avg_launch_us": 1e6 * t_launch, "launches": int(st["launches"]),
         "launches_timed_with_events": int(st["timed_launches"]),
         "algorithmic_bytes_per_move": bytes_move, "moves_per_launch": moves_per_launch,
@@ -594,8 +644,8 @@ def main():
                 rf2 = (launch_mode_roofline(r2, a, args, local_rank, 0, barrier, sh2, n_mol, box,
                                             default_parts(r2, n_mol)) if r_["server"]
                        else roofline_object(r_, r2, args, sh2, n_mol, box, default_parts(r2, n_mol)))
-                entry["units_per_move"] = ((5 if r2 == 1 else 8) if r_["server"]
-                                          else default_parts(r2, n_mol))
+                entry["units_per_move"] = ((server_lat_parts(r2, n_mol) or (5 if r2 == 1 else 8))
+                                           if r_["server"] else default_parts(r2, n_mol))
                 if rf2:
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry

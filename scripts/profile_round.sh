@@ -11,5 +11,10 @@ rocprofv3 --pmc FETCH_SIZE TCC_HIT_sum --output-format csv -d $OUT/pmc_fetch -- 
 rocprofv3 --pmc WRITE_SIZE TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --no-cpu --no-secondary --steps 40 --warmup 4 > $OUT/pmc_write.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_sq1 -- python3 $R/bench.py --no-cpu --no-secondary --steps 40 --warmup 4 > $OUT/pmc_sq1.log 2>&1 || exit 1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INST_CYCLES_VMEM --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --no-cpu --no-secondary --steps 40 --warmup 4 > $OUT/pmc_sq2.log 2>&1 || exit 1
+# the kernels that actually run BASELINE configs[1] (one chain) and the reference's call surface:
+# the persistent servers are ONE dispatch each, counters are per dispatch
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_server -- python3 $R/bench.py --no-cpu --no-secondary --replicas 1 --steps 20000 --warmup 300 > $OUT/trace_server.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM --output-format csv -d $OUT/pmc_server1 -- python3 $R/bench.py --no-cpu --no-secondary --replicas 1 --steps 20000 --warmup 300 > $OUT/pmc_server1.log 2>&1 || exit 1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_server2 -- python3 $R/bench.py --no-cpu --no-secondary --replicas 1 --steps 20000 --warmup 300 > $OUT/pmc_server2.log 2>&1 || exit 1
 echo done
 echo "now run: python3 scripts/summarize_profile.py roundN [kernel name] (in the container)"

@@ -67,7 +67,23 @@ if wc:
 if "TCC_HIT_sum" in pmc and "TCC_MISS_sum" in pmc:
     h, m = pmc["TCC_HIT_sum"]["per_dispatch"], pmc["TCC_MISS_sum"]["per_dispatch"]
     derived["l2_hit_rate"] = h / (h + m)
-json.dump({"trace": trace, "pmc": pmc, "derived": derived},
+# the roofline object's companions: what binds the kernel beside bytes
+extras = {"kernel": KERNEL, "moves_per_launch": moves_per_launch}
+if "SQ_INSTS_VALU" in pmc:
+    extras["valu_insts_per_move"] = pmc["SQ_INSTS_VALU"]["per_dispatch"] / moves_per_launch
+if wc and "SQ_ACTIVE_INST_VALU" in pmc and w:
+    n_simd = 256 * 4
+    waves_per_simd = min(w / n_simd, 8.0)
+    extras["waves_per_simd"] = waves_per_simd
+    # SQ_WAVE_CYCLES sums the resident waves' cycles; the vector pipe of a SIMD serves all of its
+    # waves, so its busy share is issue cycles x waves per SIMD / wave cycles
+    extras["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["per_dispatch"] * waves_per_simd / wc
+    extras["clock_ghz"] = wc / waves_per_simd / n_simd / (trace["avg_us"] * 1e3)
+if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+    hbm = (2 * pmc["FETCH_SIZE"]["per_dispatch"] + pmc["WRITE_SIZE"]["per_dispatch"]) * 1024
+    extras["hbm_traffic_gbs"] = hbm / (trace["avg_us"] * 1e-6) / 1e9
+    extras["hbm_traffic_frac"] = extras["hbm_traffic_gbs"] / 8000.0
+json.dump({"trace": trace, "pmc": pmc, "derived": derived, "roofline_extras": extras},
           open(os.path.join(DST, f"{TAG}_default_pmc_summary.json"), "w"), indent=1)
 
 fetch = pmc["FETCH_SIZE"]["per_dispatch"]
@@ -91,6 +107,49 @@ if bench.get("roofline") and bench["roofline"].get("kernel") == KERNEL:
                                            "passes of the same profiling session (scripts/profile_round.sh); "
                                            "filled in by scripts/summarize_profile.py, not measured by this run")
     json.dump(bench, open(os.path.join(DST, f"{TAG}_default_bench.json"), "w"))
+# ---- the persistent move server of one chain (BASELINE configs[1]): counters of its longest dispatch
+def server_summary():
+    steps = 20000  # scripts/profile_round.sh
+    out = {"command": "bench.py --no-cpu --no-secondary --replicas 1 --steps 20000 --warmup 300",
+           "steps_of_the_dispatch": steps}
+    try:
+        tr = list(csv.DictReader(open(newest("trace_server/*/*kernel_trace.csv"))))
+    except SystemExit:
+        return None
+    srv = [r for r in tr if "k_move_server" in r["Kernel_Name"]]
+    if not srv:
+        return None
+    big = max(srv, key=lambda r: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    dur = int(big["End_Timestamp"]) - int(big["Start_Timestamp"])
+    out["kernel"] = big["Kernel_Name"].split("(")[0]
+    out["workgroups"] = int(big["Grid_Size_X"]) // int(big["Workgroup_Size_X"])
+    out["waves_per_workgroup"] = int(big["Workgroup_Size_X"]) // 64
+    out["us_per_step_in_kernel"] = dur / 1e3 / steps
+    cnt = {}
+    for name in ("pmc_server1", "pmc_server2"):
+        rows = [r for r in csv.DictReader(open(newest(f"{name}/*/*counter_collection.csv")))
+                if "k_move_server" in r["Kernel_Name"]]
+        by_disp = collections.defaultdict(dict)
+        for r in rows:
+            by_disp[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        key = "SQ_WAVE_CYCLES" if name == "pmc_server1" else "SQ_WAIT_ANY"
+        best = max(by_disp.values(), key=lambda d: d.get(key, 0.0))
+        cnt.update(best)
+    out["counters_of_the_dispatch"] = cnt
+    if "SQ_INSTS_VALU" in cnt:
+        out["valu_insts_per_step"] = cnt["SQ_INSTS_VALU"] / steps
+        out["salu_insts_per_step"] = cnt.get("SQ_INSTS_SALU", 0.0) / steps
+        out["lds_insts_per_step"] = cnt.get("SQ_INSTS_LDS", 0.0) / steps
+    if "SQ_WAVE_CYCLES" in cnt and "SQ_ACTIVE_INST_VALU" in cnt:
+        out["valu_issue_share_of_wave_cycles"] = cnt["SQ_ACTIVE_INST_VALU"] / cnt["SQ_WAVE_CYCLES"]
+        out["wait_share_of_wave_cycles"] = cnt.get("SQ_WAIT_ANY", 0.0) / cnt["SQ_WAVE_CYCLES"]
+    return out
+
+
+srv = server_summary()
+if srv:
+    json.dump(srv, open(os.path.join(DST, f"{TAG}_server_pmc_summary.json"), "w"), indent=1)
+    print({k: v for k, v in srv.items() if k != "counters_of_the_dispatch"})
 print(json.dumps(trace))
 print({k: round(v["per_dispatch"], 1) for k, v in pmc.items()})
 print({k: traffic[k] for k in ("bytes_per_launch", "bytes_per_move")})
