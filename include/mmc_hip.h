@@ -463,6 +463,25 @@ int32_t mmc_batch_run_chains(mmc_batch *b, const mmc_run_params *p, mmc_chain *c
 int32_t mmc_chain_block_line(const mmc_chain *chain, int64_t block, int64_t n_mol, double box,
                              double ideal_term, char *buf, int64_t len);
 
+/* ---- the one collective of a sharded run: RCCL over xGMI ---------------------
+ * Replicas shard over GPUs with no data-path collective; what is reduced, once per block, is a
+ * handful of observables (sums of energies and acceptance counters, the maximum of the elapsed
+ * time).  For hosts without torch (the reference's language is Julia): one process per GPU,
+ *   rank 0:    mmc_dist_unique_id(id), then id goes to the other ranks by whatever the host has (a
+ *              file, a socket, MPI);
+ *   all ranks: mmc_dist_init(rank, world, id, device, &d)      -- ncclCommInitRank, collective;
+ *              mmc_dist_reduce(d, sums, n_sum, maxima, n_max)  -- in place: two ncclAllReduce
+ *              (ncclSum / ncclMax, fp64) on the communicator's own stream;
+ *              mmc_dist_destroy(d).
+ * librccl.so is loaded at the first of these calls (MMC_ERR_UNSUPPORTED if it is not there); the
+ * library itself links libamdhip64 only. */
+typedef struct mmc_dist mmc_dist;
+int32_t mmc_dist_unique_id(uint8_t id[128]);
+int32_t mmc_dist_init(int32_t rank, int32_t world, const uint8_t id[128], int32_t device,
+                      mmc_dist **out);
+int32_t mmc_dist_reduce(mmc_dist *d, double *sums, int64_t n_sum, double *maxima, int64_t n_max);
+int32_t mmc_dist_destroy(mmc_dist *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -152,6 +152,10 @@ SIGNATURES = {
     "mmc_philox4x32": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
     "mmc_batch_run_chains": [_vp, C.POINTER(RunParams), _vp, C.c_int32, C.POINTER(RunStats)],
     "mmc_chain_block_line": [_vp, _i64, _i64, _d, _d, C.c_char_p, _i64],
+    "mmc_dist_unique_id": [C.c_char_p],                      # uint8_t[128]
+    "mmc_dist_init": [_i32, _i32, C.c_char_p, _i32, C.POINTER(_vp)],
+    "mmc_dist_reduce": [_vp, _dp, _i64, _dp, _i64],
+    "mmc_dist_destroy": [_vp],
 }
 _RESTYPE = {"mmc_last_error": C.c_char_p, "mmc_version": C.c_char_p}
 

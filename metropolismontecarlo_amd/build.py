@@ -21,7 +21,8 @@ ARCH = "gfx950"
 SOURCES = ["mmc_hip.hip"]
 DEPS = ["mmc_hip.hip", "mmc_wave_unit.inc", "mmc_host.hpp", "mmc_device.hpp", "mmc_kernels.hpp", "mmc_fast.hpp", "mmc_total.hpp", "mmc_wave.hpp",
         "mmc_propose.hpp", "mmc_study.hpp", "mmc_system.inc",
-        "mmc_ctx.inc", "mmc_batch.inc", "mmc_engine.inc"]
+        "mmc_ctx.inc", "mmc_batch.inc", "mmc_engine.inc", "mmc_dist.inc", "mmc_ctxsrv.hpp",
+        "mmc_lat.hpp", "mmc_wave_lat.inc", "mmc_potential.hpp"]
 
 
 def _stale():
@@ -35,7 +36,7 @@ def _stale():
 def command(extra=()):
     return [HIPCC, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
             "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-o", LIB,
-            *[os.path.join(CSRC, s) for s in SOURCES], *extra]
+            *[os.path.join(CSRC, s) for s in SOURCES], "-ldl", *extra]
 
 
 def build(force=False, verbose=False):

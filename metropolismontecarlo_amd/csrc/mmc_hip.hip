@@ -8,3 +8,4 @@
 #include "mmc_ctx.inc"
 #include "mmc_batch.inc"
 #include "mmc_engine.inc"
+#include "mmc_dist.inc"

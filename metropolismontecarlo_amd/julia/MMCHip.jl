@@ -431,6 +431,33 @@ volume_change!(b::Batch, new_box::Float64, new_kappa::Float64) =
     check(ccall((:mmc_batch_volume_change, libmmc), Int32, (Ptr{Cvoid}, Float64, Float64),
                 b.h, new_box, new_kappa))
 
+# ---- the one collective of a sharded run: RCCL behind the C ABI (include/mmc_hip.h, mmc_dist_*) ----
+"""
+    id = dist_unique_id()                       # rank 0; send the 128 bytes to the other ranks
+    d  = dist_init(rank, world, id; device = rank)
+    dist_reduce!(d, sums, maxima)               # in place over all ranks: sum / max, Float64
+    dist_destroy(d)
+
+One process per GPU; replicas shard over ranks with no data-path collective, and this is the
+reduction of a block's observables (energy sums, acceptance counters; the longest elapsed time).
+"""
+function dist_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:mmc_dist_unique_id, libmmc), Int32, (Ptr{UInt8},), id))
+    return id
+end
+function dist_init(rank::Integer, world::Integer, id::Vector{UInt8}; device::Integer = 0)
+    length(id) == 128 || error("the unique id has 128 bytes")
+    d = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:mmc_dist_init, libmmc), Int32, (Int32, Int32, Ptr{UInt8}, Int32, Ptr{Ptr{Cvoid}}),
+                rank, world, id, device, d))
+    return d[]
+end
+dist_reduce!(d::Ptr{Cvoid}, sums::Vector{Float64}, maxima::Vector{Float64}) =
+    check(ccall((:mmc_dist_reduce, libmmc), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Ptr{Float64}, Int64),
+                d, sums, length(sums), maxima, length(maxima)))
+dist_destroy(d::Ptr{Cvoid}) = check(ccall((:mmc_dist_destroy, libmmc), Int32, (Ptr{Cvoid},), d))
+
 "Status line of one block as Loop() prints it (main.jl:667-679) from one chain record."
 function block_line(chain::MMCChain, block::Integer, n_mol::Integer, box::Float64;
                     ideal_term::Float64 = 4.60453)

@@ -44,10 +44,67 @@ def run_seed(phase=0):
     return BASE_SEED + 1_000_003 * int(phase)
 
 
+class RcclReducer:
+    """The reduction over the library's own RCCL communicator (mmc_dist_*, include/mmc_hip.h): what
+    a host without torch uses.  Rank 0 creates the unique id; `exchange(id_bytes_or_None)` must
+    hand every rank rank 0's 128 bytes (default: a file named by MMC_DIST_ID_FILE)."""
+
+    def __init__(self, rank, world, device=0, exchange=None):
+        import ctypes as C
+        import time
+        from . import _lib
+        self._L, self._C = _lib.lib(), C
+        ident = C.create_string_buffer(128)
+        if exchange is None:
+            path = os.environ.get("MMC_DIST_ID_FILE", "/tmp/mmc_dist_id")
+
+            def exchange(raw):
+                if raw is not None:
+                    with open(path + ".tmp", "wb") as fh:
+                        fh.write(raw)
+                    os.replace(path + ".tmp", path)
+                    return raw
+                for _ in range(6000):
+                    if os.path.exists(path) and os.path.getsize(path) == 128:
+                        return open(path, "rb").read()
+                    time.sleep(0.01)
+                raise RuntimeError("no unique id from rank 0")
+        if rank == 0:
+            _lib.check(self._L.mmc_dist_unique_id(ident))
+        raw = exchange(ident.raw if rank == 0 else None) if world > 1 else ident.raw
+        self._h = C.c_void_p()
+        _lib.check(self._L.mmc_dist_init(rank, world, C.create_string_buffer(raw, 128), device,
+                                         C.byref(self._h)))
+        self.world = world
+
+    def reduce(self, sums, maxima):
+        from . import _lib
+        dp = self._C.POINTER(self._C.c_double)
+        sums = np.ascontiguousarray(sums, dtype=np.float64)
+        maxima = np.ascontiguousarray(maxima, dtype=np.float64)
+        _lib.check(self._L.mmc_dist_reduce(self._h, sums.ctypes.data_as(dp), len(sums),
+                                           maxima.ctypes.data_as(dp), len(maxima)))
+        return sums, maxima
+
+    def close(self):
+        if self._h:
+            self._L.mmc_dist_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
 def reduce_observables(local, elapsed, dist=None, device="cpu"):
     """SUM the observable vector and MAX the elapsed time over all ranks.  `dist` is
-    torch.distributed (initialised) or None for a single process."""
+    torch.distributed (initialised), an RcclReducer, or None for a single process."""
     vec = np.array([float(local[k]) for k in OBSERVABLES], dtype=np.float64)
+    if isinstance(dist, RcclReducer):
+        s, m = dist.reduce(vec, [float(elapsed)])
+        return dict(zip(OBSERVABLES, s)), float(m[0])
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return dict(zip(OBSERVABLES, vec)), float(elapsed)
     import torch

@@ -47,3 +47,32 @@ def test_two_ranks_share_nothing_but_the_final_reduction(dist_rehearsal):
     assert two["overlaps"] == one["overlaps"]
     e2, e1 = two["energy_mean_per_replica"], one["energy_mean_per_replica"]
     assert abs(e2 - e1) < 1e-13 * abs(e1), (e2, e1)
+
+
+def test_rccl_collective_behind_the_c_abi():
+    """mmc_dist_*: the final reduction for hosts without torch.  A one-GPU box can form a
+    communicator of ONE rank only (RCCL wants a GPU per rank): that still goes through
+    ncclGetUniqueId / ncclCommInitRank / ncclAllReduce (sum and max, fp64) / ncclCommDestroy."""
+    import ctypes as C
+    import numpy as np
+    from metropolismontecarlo_amd import _lib
+    L = _lib.lib()
+    ident = C.create_string_buffer(128)
+    _lib.check(L.mmc_dist_unique_id(ident))
+    assert any(ident.raw)
+    d = C.c_void_p()
+    _lib.check(L.mmc_dist_init(0, 1, ident, 0, C.byref(d)))
+    sums = np.array([1.5, -2.25, 3e10, 0.0])
+    mx = np.array([0.125, -7.0])
+    dp = C.POINTER(C.c_double)
+    for _ in range(3):
+        _lib.check(L.mmc_dist_reduce(d, sums.ctypes.data_as(dp), 4, mx.ctypes.data_as(dp), 2))
+    assert np.array_equal(sums, [1.5, -2.25, 3e10, 0.0]) and np.array_equal(mx, [0.125, -7.0])
+    _lib.check(L.mmc_dist_reduce(d, None, 0, mx.ctypes.data_as(dp), 2))
+    _lib.check(L.mmc_dist_destroy(d))
+    # the same through sharding.reduce_observables
+    from metropolismontecarlo_amd import sharding
+    local = dict(moves=10, accepted=4, overlaps=0, energy_sum=-1.5, kernel_ms=2.0, launches=3)
+    with sharding.RcclReducer(0, 1) as red:
+        out, t = sharding.reduce_observables(local, 0.25, red)
+    assert out["moves"] == 10 and out["energy_sum"] == -1.5 and t == 0.25

@@ -105,7 +105,8 @@ C2J = {
     "void*": "Ptr{Cvoid}", "mmc_ctx*": "Ptr{Cvoid}", "mmc_batch*": "Ptr{Cvoid}",
     "mmc_ctx**": "Ptr{Ptr{Cvoid}}", "mmc_batch**": "Ptr{Ptr{Cvoid}}",
     "double*": "Ptr{Float64}", "int64_t*": "Ptr{Int64}", "int32_t*": "Ptr{Int32}",
-    "uint32_t*": "Ptr{UInt32}", "uint64_t*": "Ptr{UInt64}",
+    "uint32_t*": "Ptr{UInt32}", "uint64_t*": "Ptr{UInt64}", "uint8_t*": "Ptr{UInt8}",
+    "mmc_dist*": "Ptr{Cvoid}", "mmc_dist**": "Ptr{Ptr{Cvoid}}",
     "constchar*": "Cstring", "char*": "Ptr{UInt8}",
     "mmc_totals*": "Ptr{MMCTotals}", "mmc_move*": "Ptr{MMCMove}",
     "mmc_move_result*": "Ptr{MMCMoveResult}", "mmc_run_params*": "Ptr{MMCRunParams}",
