@@ -428,7 +428,7 @@ def call_surface(a, n_moves=2000, n_warm=300):
                 "acceptance": n_acc / n_moves, "energy_drift_rel": drift,
                 "per_move": {k: (st1[k] - st0[k]) / n_moves
                              for k in ("cmds", "cache_hits", "spec_hits", "spec_miss",
-                                       "launch_evals")},
+                                       "launch_evals", "look_ahead_hits")},
                 "server_round_trip_us": ping}
 
     out = {"workload": "ONE chain, SPC/E 750 molecules: the body of Loop() (Ewald/main.jl:487-644) "

@@ -189,11 +189,14 @@ int32_t mmc_call_ewald_short(mmc_ctx *ctx, int64_t i, const double *com, const d
 int32_t mmc_call_recip_move(mmc_ctx *ctx, const double *r_old, const double *r_new,
                             const double *q, int64_t n, const double *sum_old, double *sum_new,
                             double *d_energy);
-/* Counters of the context: out[0..7] = commands answered by the persistent kernel, launches of it,
+/* Counters of the context: out[0..9] = commands answered by the persistent kernel, launches of it,
  * commands that had to be repeated on a fresh one, per-molecule calls answered from the cached
  * evaluation, RecipMoves answered from the speculative sum, speculative sums that went unused,
- * evaluations by ordinary launch, 1 if the persistent kernel is running. */
-int32_t mmc_ctx_stats(mmc_ctx *ctx, int64_t out[8]);
+ * evaluations by ordinary launch, 1 if the persistent kernel is running, evaluations answered by
+ * the look-ahead (the command that evaluates a moved molecule i also has molecule i + 1 -- the next
+ * of Loop()'s sweep, main.jl:490 -- evaluated by a second set of workgroups; valid if nothing
+ * changes before it is asked for, i.e. the move was accepted), look-aheads posted. */
+int32_t mmc_ctx_stats(mmc_ctx *ctx, int64_t out[10]);
 /* Test hook / measurement: average round trip in microseconds of n empty commands through the
  * running persistent kernel -- the floor under every served call. */
 int32_t mmc_ctx_ping(mmc_ctx *ctx, int64_t n, double *us_avg);

@@ -8,22 +8,26 @@
 // move server of the replica batch (k_move_server_wave) showed that a resident kernel answers in
 // well under half of that.  This is the same scheme behind the context API:
 //
-//   * the host posts a COMMAND BLOCK in pinned memory (CtxCmd: which molecule, its coordinates as
-//     the caller's arrays hold them, up to CS_MAX_PEND molecules whose device copy is stale, which
-//     terms are wanted) and bumps the sequence number in the block's head word, written last;
-//   * every workgroup of the server polls the head word (one lane, system-scope loads), reads the
-//     block, writes the stale molecules' records ITSELF -- each workgroup's stores go through its
-//     own XCD's L2, so no cross-workgroup visibility protocol is needed; they all write the same
-//     bytes -- and evaluates its share of the parts with the unit body of k_move_eval_wave
-//     (mmc_wave_unit.inc): one wave per part, pair parts split the molecule range, the last part
-//     is the reciprocal sum;
-//   * every wave stores its own 64-byte PartOut (stamp + checksum, write-through) into pinned
-//     memory; the host combines the parts in index order.
+//   * the host posts a COMMAND BLOCK in pinned memory (which molecule, its coordinates as the
+//     caller's arrays hold them, up to CS_MAX_PEND molecules whose device copy is stale, which
+//     terms are wanted): eight 64-byte lines, each closed by a tag that repeats the sequence
+//     number, the head word written last;
+//   * every workgroup of the server reads the whole block with one load per lane (system scope)
+//     until head and tags carry the number it waits for, writes the stale molecules' records
+//     ITSELF -- each workgroup's stores go through its own XCD's L2, so no cross-workgroup
+//     visibility protocol is needed; they all write the same bytes -- and evaluates its share of
+//     the parts: k_ctx_server_lat with the latency body (mmc_wave_lat.inc: resident molecule
+//     ranges, one 64-byte record per workgroup), k_ctx_server with the unit body of
+//     k_move_eval_wave (one record per wave) where a range does not fit a wave's storage;
+//   * the records (stamp + checksum, write-through) land in pinned memory; the host combines them
+//     in index order.
 // One command evaluates LJ and real-space Coulomb TOGETHER (the host caches the pair for the
 // second of LJ_poly_dU / EwaldShort), for one state or for two (mmc_trial_move), and -- when the
 // molecule's old coordinates are known -- RecipMove as well, speculatively: S_new goes to a free
 // structure-factor buffer and to its pinned host mirror, so that the RecipMove call that follows is
-// a comparison of arrays on the host.
+// a comparison of arrays on the host.  A second set of workgroups (look-ahead) evaluates, with the
+// command of a moved molecule i, molecule i + 1 of Loop()'s sweep as the system then stands: if the
+// move is kept, the next LJ_poly_dU / EwaldShort pair is answered without a command.
 //
 // Every wait is bounded: a workgroup that sees no command for CS_IDLE_TICKS raises its flag and
 // exits; the host never posts to a server it has not heard from for a third of that time without
@@ -37,6 +41,7 @@
 #define CS_TWO 2u    // ... in both states of the record (old and new); else the new slot only
 #define CS_RECIP 4u  // reciprocal part: S[s_dst] = S[s_base] + dS(old -> new), dE against S[s_base]
 #define CS_QUIT 8u
+#define CS_NEXT 16u  // the look-ahead workgroups evaluate molecule `mol2` (one state, its device record) as well
 #define CS_IDLE_TICKS 100000000ULL // 1 s of the 100 MHz real-time counter
 
 // The command block: 64 words of 8 bytes = eight 64-byte lines; the LAST word of every line is a
@@ -46,7 +51,7 @@
 // -- a line whose tag is current holds current data -- so a command costs one PCIe read round
 // trip, not a poll plus a fetch.  Logical word L sits at physical word CS_PHYS(L):
 //   [0]      head: seq << 16 | flags
-//   [1]      lo: mol (0-based)   hi: n_pend
+//   [1]      lo: mol (0-based)   hi: n_pend | mol2 << 4   (mol2: CS_NEXT)
 //   [2]      lo: s_base | s_dst << 8              hi: launch stamp of the results
 //   [3..27]  the first 25 words of a MoveRec: mol + 1, com_new, atoms_new, com_old, atoms_old
 //   [28]     lo: pend_mol[0]  hi: pend_mol[1]    (0-based)
@@ -252,12 +257,17 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += LAT_WAVES * 64)
         ls.qtab[k] = qq_tab[k];
-    const int r = 0, g = blockIdx.x;
+    // workgroups [0, G): the command's evaluation; [G, 2 G) (when launched): LOOK-AHEAD -- the same
+    // part plan, evaluating the molecule the host expects to be asked about next (CS_NEXT) in the
+    // state this command leaves behind.  Their records (out[4 + g]) are collected by the host
+    // when and if that call comes; nobody waits for them.
+    const int G = n_parts / LAT_WAVES;
+    const int r = 0, role = (int)blockIdx.x / G, g = (int)blockIdx.x - role * G;
     double *const myrec = rec;
     const uint16_t *const cq_base = bv.comq;
     LAT_WAVE_SETUP(g * LAT_WAVES + wv, myrec, cq_base)
     __syncthreads();
-    const bool wg_has_recip = (g + 1) * LAT_WAVES > plan.np;
+    const bool wg_has_recip = role == 0 && (g + 1) * LAT_WAVES > plan.np;
 
     for (unsigned long long seq = sa.seq0;; seq++) {
         asm volatile("" : "+v"(lane));
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
             }
             if (gave_up || (head & CS_QUIT)) {
                 if (lane == 0) {
-                    __hip_atomic_store(sa.state + 1 + g, gave_up ? 1 : 2, __ATOMIC_RELAXED,
+                    __hip_atomic_store(sa.state + 1 + blockIdx.x, gave_up ? 1 : 2, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
                     if (gave_up)
                         __hip_atomic_store(sa.state, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -301,7 +311,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
         // molecules whose device copy is stale: every wave refreshes its resident range, one wave
         // of the workgroup writes the global copies
         {
-            const int n_pend = __builtin_amdgcn_readfirstlane((int)(cw[CS_PHYS(CS_W_MOL)] >> 32));
+            const int n_pend = __builtin_amdgcn_readfirstlane((int)(cw[CS_PHYS(CS_W_MOL)] >> 32)) & 15;
             const unsigned long long pmw = cw[CS_PHYS(CS_W_PMOL)];
             for (int p = 0; p < n_pend && p < CS_MAX_PEND; p++) {
                 const int pm = __builtin_amdgcn_readfirstlane(p == 0 ? (int)pmw : (int)(pmw >> 32));
@@ -311,6 +321,37 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
                 if (wv == 0)
                     LAT_COMMIT_GLOBAL(0, pm, val, myrec);
             }
+        }
+        if (role == 1) { // ---- look-ahead: molecule mol2, one state, no reciprocal part ----
+            if (!(flags & CS_NEXT))
+                continue;
+            const int i0 = (int)((unsigned)__builtin_amdgcn_readfirstlane((int)(cw[CS_PHYS(CS_W_MOL)] >> 32)) >> 4);
+            const unsigned stamp = (unsigned)__builtin_amdgcn_readfirstlane((int)(cw[CS_PHYS(CS_W_SBUF)] >> 32))
+                                   & MMC_STAMP_MASK;
+            // its record as the device holds it (this workgroup's own commit stores above came
+            // first; the host never names a molecule here whose device copy is stale)
+            double cur = 0.0;
+            if (lane < MMC_REC)
+                cur = myrec[(int64_t)i0 * MMC_RSTRIDE + lane];
+            const double w = __shfl(cur, (lane >= MV_AT_NEW && lane < MV_AT_NEW + 9) ? lane - MV_AT_NEW
+                                         : (lane >= MV_COM_NEW && lane < MV_COM_NEW + 3) ? 9 + lane - MV_COM_NEW : 0, 64);
+            unsigned long long s_sum_out = 0;
+            (void)s_sum_out;
+            {
+                const bool part_pairs = do_pairs;
+                const bool do_pairs = part_pairs, do_recip = false;
+#define WV_S_BASE s_buf(bv, 0, 0)
+#define WV_S_DST s_buf(bv, 0, 0)
+#define WV_NS 1
+#include "mmc_wave_lat.inc"
+#undef WV_NS
+#undef WV_S_DST
+#undef WV_S_BASE
+            }
+            __syncthreads();
+            if (wv == 0)
+                lat_store_combined<true>(ls, out + 4 + g, lane, stamp);
+            continue;
         }
         const unsigned long long wmol = cw[CS_PHYS(CS_W_MOL)], wsb = cw[CS_PHYS(CS_W_SBUF)];
         const int i0 = __builtin_amdgcn_readfirstlane((int)wmol);

@@ -258,10 +258,10 @@ class Context:
 
     def stats(self):
         """mmc_ctx_stats: counters of the context's engine (persistent kernel, cache, speculation)."""
-        st = (C.c_int64 * 8)()
+        st = (C.c_int64 * 10)()
         check(self._L.mmc_ctx_stats(self._h, st))
         return dict(zip(("cmds", "launches", "retries", "cache_hits", "spec_hits", "spec_miss",
-                         "launch_evals", "alive"), list(st)))
+                         "launch_evals", "alive", "look_ahead_hits", "look_ahead_posted"), list(st)))
 
     def set_option(self, key, value):
         check(self._L.mmc_ctx_set_option(self._h, key.encode(), int(value)))

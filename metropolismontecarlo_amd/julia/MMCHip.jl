@@ -294,7 +294,7 @@ reject_move!() = check(ccall((:mmc_reject_move, libmmc), Int32, (Ptr{Cvoid},), s
 
 "Counters of the context (mmc_ctx_stats): commands served, launches, retries, cache hits, ..."
 function stats()
-    out = zeros(Int64, 8)
+    out = zeros(Int64, 10)
     check(ccall((:mmc_ctx_stats, libmmc), Int32, (Ptr{Cvoid}, Ptr{Int64}), session().ctx, out))
     return out
 end

@@ -47,7 +47,7 @@ tm = np.zeros(5); n = 300
 loop(n, tm)
 import ctypes
 from metropolismontecarlo_amd import api as _api
-st = (ctypes.c_int64 * 8)()
+st = (ctypes.c_int64 * 10)()
 sess = list(_api._sessions.values())[0]
 sess._L.mmc_ctx_stats(sess._h, st)
 print("ctx stats [cmds, launches, retries, cache hits, spec hits, spec miss, launch evals, alive]:", list(st))

@@ -155,10 +155,10 @@ def test_reference_asserts_surface_as_assertion_errors():
 def _ctx_stats(ewald):
     import ctypes
     s = ewald._session
-    st = (ctypes.c_int64 * 8)()
+    st = (ctypes.c_int64 * 10)()
     assert s._L.mmc_ctx_stats(s._h, st) == 0
     return dict(zip(("cmds", "launches", "retries", "cache_hits", "spec_hits", "spec_miss",
-                     "launch_evals", "alive"), list(st)))
+                     "launch_evals", "alive", "look_ahead_hits", "look_ahead_posted"), list(st)))
 
 
 def _oracle_state(a, moa, soa, orc):
@@ -298,3 +298,68 @@ def test_server_and_launch_paths_agree(orc):
             res.append(np.concatenate([np.ravel(x) for x in out]))
     scale = np.maximum(np.abs(res[0]), 1.0)
     assert (np.abs(res[0] - res[1]) / scale).max() < 1e-11
+
+
+def test_look_ahead_answers_the_next_molecule_of_a_sweep(orc):
+    """Loop() sweeps the molecules in order (main.jl:490).  The command that evaluates a moved
+    molecule i also has molecule i + 1 evaluated by the server's second set of workgroups; when
+    the move is accepted (nothing changes before the next call) LJ_poly_dU(i + 1) / EwaldShort(i + 1)
+    are answered from those records -- the same values a command of their own gives -- and when
+    it is rejected (the molecule is restored) they are not used."""
+    a = common.nist_arrays(4, "unwrapped")
+    moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+    potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+    ewo = orc.Ewald(5.6 / box, 5, 27, box)
+    rng = np.random.default_rng(12)
+    direct = {}
+    for i in range(1, 41):
+        f, l = moa.firstAtom[i - 1], moa.lastAtom[i - 1]
+        s0 = _oracle_state(a, moa, soa, orc)
+        st0 = _ctx_stats(ewald)
+        e_old, _ = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+        q_old, _, _ = EwaldShort(i, moa, soa, totProps, ewald, box)
+        st1 = _ctx_stats(ewald)
+        eo, _ = orc.lj_poly_du(i, s0, RCUT)
+        qo, _, _ = orc.ewald_short(i, s0, ewo, RCUT)
+        assert rel(e_old, eo) < TOL and rel(q_old, qo) < TOL, i
+        accepted_before = i > 1 and (i - 1) % 4 != 0
+        if i > 1:   # answered by the look-ahead exactly when the previous move was kept
+            assert (st1["look_ahead_hits"] - st0["look_ahead_hits"] == 1) == accepted_before, i
+            assert (st1["cmds"] - st0["cmds"] == 0) == accepted_before, i
+        direct[i] = (e_old, q_old)
+        rm_old, ra_old = moa.COM[i - 1].copy(), soa.coords[f - 1:l].copy()
+        d = (rng.random(3) - 0.5) * 0.3
+        moa.COM[i - 1] += d
+        soa.coords[f - 1:l] += d
+        LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+        EwaldShort(i, moa, soa, totProps, ewald, box)
+        if i % 4 == 0:  # rejected: Loop restores the molecule
+            moa.COM[i - 1] = rm_old
+            soa.coords[f - 1:l] = ra_old
+    st = _ctx_stats(ewald)
+    assert st["look_ahead_posted"] == 40 and st["look_ahead_hits"] == 30 and st["retries"] == 0
+    # the look-ahead's numbers are the numbers of a command of its own: same kernel, plan and sums
+    release_sessions()
+    import os
+    os.environ["MMC_CTX_LOOKAHEAD"] = "0"
+    try:
+        moa, soa, vdwTable, ewald, totProps, box = reference_setup(a)
+        potential(moa, soa, Properties(), ewald, vdwTable, totProps, "ewald")
+        rng = np.random.default_rng(12)
+        for i in range(1, 41):
+            f, l = moa.firstAtom[i - 1], moa.lastAtom[i - 1]
+            e_old, _ = LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+            q_old, _, _ = EwaldShort(i, moa, soa, totProps, ewald, box)
+            assert (e_old, q_old) == direct[i], i          # bit for bit
+            rm_old, ra_old = moa.COM[i - 1].copy(), soa.coords[f - 1:l].copy()
+            d = (rng.random(3) - 0.5) * 0.3
+            moa.COM[i - 1] += d
+            soa.coords[f - 1:l] += d
+            LJ_poly_ΔU(i, moa, soa, vdwTable, RCUT, box)
+            EwaldShort(i, moa, soa, totProps, ewald, box)
+            if i % 4 == 0:
+                moa.COM[i - 1] = rm_old
+                soa.coords[f - 1:l] = ra_old
+        assert _ctx_stats(ewald)["look_ahead_posted"] == 0
+    finally:
+        os.environ.pop("MMC_CTX_LOOKAHEAD", None)
