@@ -479,7 +479,7 @@ def main():
                     help="replica groups pipelined per GPU (0 = 2, or 1 for a single chain)")
     ap.add_argument("--parts", type=int, default=0, help="units per replica-move (0=auto)")
     ap.add_argument("--threads", type=int, default=0,
-                    help="host threads per GPU for the accept/reject (0 = min(4, cores / ranks))")
+                    help="host threads per GPU for the accept/reject (0 = min(8, cores / ranks))")
     ap.add_argument("--kernel", type=int, default=3,
                     help="3 = by launch size (default), 2 = wave per move, 1 = workgroup per move, "
                          "0 = generic")
@@ -513,7 +513,7 @@ def main():
         # every rank spins its own worker threads: never oversubscribe the node's cores
         cores = len(os.sched_getaffinity(0))
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.threads = max(1, min(4, (cores - local_world) // max(local_world, 1)))
+        args.threads = max(1, min(8, (cores - local_world) // max(local_world, 1)))
 
     import torch
     import torch.distributed as dist

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += blockDim.x)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += blockDim.x)
         sm.qtab[k] = qq_tab[k];
     __syncthreads();
 
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
     const int tid = threadIdx.x, lane0 = tid & 63;
     int lane = lane0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += LAT_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += LAT_WAVES * 64)
         ls.qtab[k] = qq_tab[k];
     // workgroups [0, G): the command's evaluation; [G, 2 G) (when launched): LOOK-AHEAD -- the same
     // part plan, evaluating the molecule the host expects to be asked about next (CS_NEXT) in the

@@ -134,6 +134,15 @@ __device__ __forceinline__ bool wave_any(bool p)
 // ~45 instructions and 16 registers instead of ocml's ~200 / 60 (whose Payne-Hanek path for huge
 // arguments is what costs).  An atom more than 1e5 box lengths outside its box is first folded
 // back by whole periods, at the accuracy such a coordinate has left.
+// A double constant materialised in scalar registers where it is used (two s_mov_b32): the
+// persistent wave kernels sit at their register limits, and LLVM otherwise hoists the constants of
+// this polynomial out of the unit loop into VGPRs that it then spills to scratch -- every reload a
+// trip to memory in the middle of a dependent chain (11 of them per unit in round 2's build).
+__device__ __forceinline__ double scalar_const(double c)
+{
+    asm volatile("" : "+s"(c));
+    return c;
+}
 __device__ __forceinline__ void sincos_moderate(double x, double &sn, double &cs)
 {
     if (!(fabs(x) < 8.0e5))
@@ -143,23 +152,33 @@ __device__ __forceinline__ void sincos_moderate(double x, double &sn, double &cs
     r = fma(-fn, 6.07710050650619224932e-11, r);                     // pio2_1t
     const int n = (int)fn;
     const double z = r * r;
-    double ps = 1.58969099521155010221e-10;                           // S6
-    ps = fma(ps, z, -2.50507602534068634195e-08);
-    ps = fma(ps, z, 2.75573137070700676789e-06);
-    ps = fma(ps, z, -1.98412698298579493134e-04);
-    ps = fma(ps, z, 8.33333333332248946124e-03);
-    ps = fma(ps, z, -1.66666666666666324348e-01);                     // S1
+    double ps = scalar_const(1.58969099521155010221e-10);             // S6
+    ps = fma(ps, z, scalar_const(-2.50507602534068634195e-08));
+    ps = fma(ps, z, scalar_const(2.75573137070700676789e-06));
+    ps = fma(ps, z, scalar_const(-1.98412698298579493134e-04));
+    ps = fma(ps, z, scalar_const(8.33333333332248946124e-03));
+    ps = fma(ps, z, scalar_const(-1.66666666666666324348e-01));       // S1
     const double s = fma(z * r, ps, r);
-    double pc = -1.13596475577881948265e-11;                          // C6
-    pc = fma(pc, z, 2.08757232129817482790e-09);
-    pc = fma(pc, z, -2.75573143513906633035e-07);
-    pc = fma(pc, z, 2.48015872894767294178e-05);
-    pc = fma(pc, z, -1.38888888888741095749e-03);
-    pc = fma(pc, z, 4.16666666666666019037e-02);                      // C1
+    double pc = scalar_const(-1.13596475577881948265e-11);            // C6
+    pc = fma(pc, z, scalar_const(2.08757232129817482790e-09));
+    pc = fma(pc, z, scalar_const(-2.75573143513906633035e-07));
+    pc = fma(pc, z, scalar_const(2.48015872894767294178e-05));
+    pc = fma(pc, z, scalar_const(-1.38888888888741095749e-03));
+    pc = fma(pc, z, scalar_const(4.16666666666666019037e-02));        // C1
     const double c = fma(z * z, pc, fma(-0.5, z, 1.0));
     const double a = (n & 1) ? c : s, b = (n & 1) ? s : c;
     sn = (n & 2) ? -a : a;
     cs = ((n + 1) & 2) ? -b : b;
+}
+
+// lane `src`'s value in every lane (ds_bpermute; no lane id involved, unlike __shfl, whose
+// __lane_id() LLVM hoists out of a persistent loop and keeps in a register for the kernel's life)
+__device__ __forceinline__ double wave_pick(double v, int src)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute(src << 2, (int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 __device__ __forceinline__ double wave_sum(double v)

@@ -39,6 +39,8 @@
 #define MMC_QQ_DEG 9
 #define MMC_QQ_NCOEF (MMC_QQ_DEG + 1)
 #define MMC_QQ_NINT 160   // 10 octaves [2^-2, 2^8) x 16 sub-intervals
+#define MMC_QQ_NROW (MMC_QQ_NINT + 1) // ... and a row of zeros: where a masked-out evaluation lands
+#define MMC_QQ_TABLE_DOUBLES (MMC_QQ_NROW * MMC_QQ_NCOEF)
 #define MMC_QQ_UMIN 0.25
 #define MMC_QQ_UMAX 256.0    // the host selects this kernel only if r_cut^2 + 100 <= UMAX,
 #define MMC_QQ_XMAX 4.0      // kappa * sqrt(r_cut^2 + 100) <= XMAX (degree 9 is enough there)
@@ -66,6 +68,8 @@ struct FastConsts {
     int32_t n_ljp;
     double q[3];
     double eps9[9], sig9[9];   // the LJ table by atom pair 3a + b (k_move_eval_wave)
+    int32_t qneg_mask;         // bit ab: q_a q_b < 0 (ewalds.jl:359, the overlap sentinel's pairs)
+    int32_t lj_mask;           // bit ab: eps > 0.001 (energy.jl:270)
 };
 
 // Horner in t over one piece's 10 coefficients, read as five 16-byte pairs: ds_read_b128 moves
@@ -89,16 +93,19 @@ __device__ __forceinline__ double qq_horner(const double *c, double t)
     return acc;
 }
 
-// piece index and position t in [-1, 1) inside the piece from the bits of u: the piece is the
-// exponent and the top 4 mantissa bits (0 at u = 0.25); the other 48 mantissa bits, shifted up by
-// 4, are the mantissa of d in [1, 2) and t = 2 d - 3.
+// piece index and offset d = u - (centre of the piece) from the bits of u: the piece is the
+// exponent and the top 4 mantissa bits (0 at u = 0.25), its centre those bits with the next one set
+// -- three instructions, and the subtraction is exact.  The coefficients of a row are those of the
+// polynomial in t = d / (half width) in [-1, 1), scaled by the powers of the half width: a power of
+// two, so Horner in d gives bit for bit what Horner in t gives on the unscaled coefficients
+// (k_build_qq_table).
 __device__ __forceinline__ double qq_piece(double u, int &idx)
 {
     const unsigned lo = (unsigned)__double_as_longlong(u), hi = (unsigned)(__double_as_longlong(u) >> 32);
     idx = (int)(hi >> 16) - 0x3FD0;
-    const unsigned dhi = (__builtin_amdgcn_alignbit(hi, lo, 28) & 0xFFFFFu) | 0x3FF00000u;
-    const double d = __longlong_as_double((long long)(((unsigned long long)dhi << 32) | (lo << 4)));
-    return fma(2.0, d, -3.0);
+    const unsigned chi = (hi & 0xFFFF0000u) | 0x8000u;
+    (void)lo;
+    return u - __longlong_as_double((long long)((unsigned long long)chi << 32));
 }
 
 // f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t.
@@ -116,6 +123,32 @@ __device__ __forceinline__ double qq_table_eval_clamped(const double *tab, doubl
     int idx;
     const double t = qq_piece(u, idx);
     idx = min(max(idx, 0), MMC_QQ_NINT - 1);
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
+}
+
+// (keep as a lane mask in an SGPR pair, the way the wave kernels hold their gates: the select reads
+// it directly.  4.0f as a high word is 2^9 <= u < 2^10: beyond the table, finite.)
+__device__ __forceinline__ double qq_table_eval_lanes(const double *tab, double u, unsigned long long keep)
+{
+    const unsigned lo = (unsigned)__double_as_longlong(u);
+    unsigned hi = (unsigned)(__double_as_longlong(u) >> 32);
+    asm("v_cndmask_b32_e64 %0, 4.0, %1, %2" : "=v"(hi) : "v"(hi), "s"(keep));
+    int idx;
+    const double t = qq_piece(__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), idx);
+    idx = min(max(idx, 0), MMC_QQ_NINT); // row NINT: zeros
+    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
+}
+
+// ... and with the discarding done by the table: a lane with keep == false evaluates the row of
+// zeros (one v_cndmask on the high word of u instead of a 64-bit select of the result), so the
+// caller adds e * (q_a q_b) unconditionally -- e is +-0 there, and x + 0 * q == x bit for bit.
+__device__ __forceinline__ double qq_table_eval_masked(const double *tab, double u, bool keep)
+{
+    const unsigned lo = (unsigned)__double_as_longlong(u);
+    const unsigned hi = keep ? (unsigned)(__double_as_longlong(u) >> 32) : 0x7FE00000u; // finite: 0 * d stays 0
+    int idx;
+    const double t = qq_piece(__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), idx);
+    idx = min(max(idx, 0), MMC_QQ_NINT); // row NINT: zeros
     return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
 }
 
@@ -167,8 +200,13 @@ __device__ __noinline__ double qq_pair_cold(double u, double kappa)
 __global__ void k_build_qq_table(double kappa, double *tab)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= MMC_QQ_NINT)
+    if (idx >= MMC_QQ_NROW)
         return;
+    if (idx == MMC_QQ_NINT) { // the row of zeros (qq_table_eval_masked)
+        for (int j = 0; j < MMC_QQ_NCOEF; j++)
+            tab[idx * MMC_QQ_NCOEF + j] = 0.0;
+        return;
+    }
     const int e = idx / 16 - 2, k = idx % 16;
     const double ua = ldexp(1.0 + k / 16.0, e), ub = ldexp(1.0 + (k + 1) / 16.0, e);
     const double uc = 0.5 * (ua + ub), uh = 0.5 * (ub - ua);
@@ -202,8 +240,9 @@ __global__ void k_build_qq_table(double kappa, double *tab)
             tc[j] = tn[j];
         }
     }
+    // Horner runs in d = u - uc = t * uh, uh = 2^(e - 5): the scaling is exact
     for (int j = 0; j < N; j++)
-        tab[idx * N + j] = m[j];
+        tab[idx * N + j] = ldexp(m[j], -j * (e - 5));
 }
 
 // Evaluate the erfc(kappa r)/r approximation at arbitrary r^2 (accuracy tests, mmc_batch_qq_table).
@@ -260,7 +299,7 @@ struct FastShared {
     alignas(16) double tile[MMC_TILE * MMC_REC]; // neighbour records, written as double2
     alignas(16) double mvw[MV_WORDS + 1];        // this replica's move record
     alignas(16) double pvw[MV_WORDS + 1];        // its previous move record (pending commit)
-    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     cplx ptab[2][3][3][MMC_NKTAB];
     double red[7 * MMC_WAVES];
     double qq9[9], ljp_eps[9], ljp_sig[9];
@@ -309,7 +348,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
         sm.ljp_ab[t] = fc.ljp_ab[t];
     }
     if (do_pairs)
-        for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += MMC_BLOCK)
+        for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += MMC_BLOCK)
             sm.qtab[k] = qq_tab[k];
     // first centres of mass of this wave's share of the COM scan
     const int len0 = min(MMC_FLIST_CAP, j_end - j_begin);

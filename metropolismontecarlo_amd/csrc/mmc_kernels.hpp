@@ -79,11 +79,15 @@ __device__ __forceinline__ uint32_t com_quant_dist2(uint32_t xy, uint32_t z, uin
     return (uint32_t)__builtin_amdgcn_sdot2(ds, ds, dz * dz, false);
 }
 
-__device__ __forceinline__ void comq_store(const BatchView &b, int r, int j, int d, double v)
+__device__ __forceinline__ void comq_store(const BatchView &b, int r, int j, int d, double v, double inv_box)
 {
     if (b.comq)
         b.comq[(int64_t)r * 3 * b.cq_stride + (d < 2 ? 2 * j + d : 2 * b.cq_stride + j)] =
-            com_quant(v, 1.0 / b.box);
+            com_quant(v, inv_box);
+}
+__device__ __forceinline__ void comq_store(const BatchView &b, int r, int j, int d, double v)
+{
+    comq_store(b, r, j, d, v, 1.0 / b.box);
 }
 
 __device__ __forceinline__ SysView sys_view(const BatchView &b, int r)

@@ -21,7 +21,7 @@
 #define LAT_KIT 6       // k-iterations (64 vectors each) a reciprocal part may have: all 337 vectors
 
 struct LatShared {
-    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     alignas(16) double lrec[LAT_WAVES][LAT_MAXMOL * MMC_REC]; // the waves' resident records
     cplx ptab[LAT_WAVES][2][3][3][MMC_NKTAB];
     uint16_t list[LAT_WAVES][LAT_MAXMOL];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_eval_lat(
     const int tid = threadIdx.x, lane0 = tid & 63;
     int lane = lane0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += LAT_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += LAT_WAVES * 64)
         ls.qtab[k] = qq_tab[k];
     const int r = r_base + blockIdx.y, g = blockIdx.x;
     double *const myrec = rec + (int64_t)r * bv.n_mol * MMC_RSTRIDE;
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
     const int tid = threadIdx.x, lane0 = tid & 63;
     int lane = lane0;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += LAT_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += LAT_WAVES * 64)
         ls.qtab[k] = qq_tab[k];
     const int G = n_parts / LAT_WAVES;
     const int r = blockIdx.x / G, g = blockIdx.x - r * G;

@@ -30,7 +30,7 @@ struct TotalPart {
 struct TotalShared {
     alignas(16) double ti[MMC_TM * MMC_REC]; // 6 KB each; ti doubles as reduction scratch
     alignas(16) double tj[MMC_TM * MMC_REC];
-    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     double red[4];
     double qq9[9], ljp_eps[9], ljp_sig[9];
     uint16_t list[MMC_TM * MMC_TM];
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_total_pairs(BatchView bv, const d
     for (int g = tid; g < nj * 6; g += MMC_BLOCK)
         *reinterpret_cast<double2 *>(&sm.tj[2 * g]) = *reinterpret_cast<const double2 *>(
             myrec + (int64_t)(j0 + g / 6) * MMC_RSTRIDE + 2 * (g % 6));
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += MMC_BLOCK)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += MMC_BLOCK)
         sm.qtab[k] = qq_tab[k];
     if (tid < 9) {
         sm.qq9[tid] = fc.qq9[tid];

@@ -47,7 +47,7 @@
 #endif
 
 template <int NW> struct WaveSharedT {
-    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     cplx ptab[NW][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
     int32_t list[NW][WV_LIST];
     alignas(16) double pvw[NW][12];    // pending commit of the unit's replica, record layout
@@ -85,6 +85,17 @@ __device__ __forceinline__ int lane_i32(int v, int src)
     return __builtin_amdgcn_readlane(v, src);
 }
 
+// a value every lane holds alike, moved to scalar registers for good (through asm: the compiler
+// cannot fall back on the vector copy, which it would keep alive -- and spill -- beside this one)
+__device__ __forceinline__ double uniform_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    unsigned lo, hi;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(lo) : "v"((int)b));
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(hi) : "v"((int)(b >> 32)));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // lane `src`'s double as a wave-uniform value (two v_readlane_b32 -> an SGPR pair)
 __device__ __forceinline__ double lane_f64(double v, int src)
 {
@@ -116,6 +127,10 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
 // g * WV_WAVES + w, + gridDim.x * WV_WAVES, ...  Unit u = (replica r_base + u / n_parts,
 // part u % n_parts); part semantics as k_move_eval (the last part of n_parts > 1 does the
 // reciprocal part, the others split the molecule range).
+// SUBST = false (launches with n_parts == 1 only): the wave that writes a pending commit to memory
+// is the only reader of that replica in the launch -- it waits for its own stores (same compute
+// unit, same L1) instead of substituting the pending words in every gather and scan block.
+template <bool SUBST>
 __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += WV_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += WV_WAVES * 64)
         sm.qtab[k] = qq_tab[k];
     __syncthreads(); // the only workgroup barrier: from here on the waves are independent
 
@@ -137,15 +152,20 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     const int plen = (n_mol + np - 1) / np;
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
     // prefilter of the COM scan: 16-bit box fractions (com_quant, mmc_kernels.hpp)
-    const double inv_box = 1.0 / box;
-    const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
+    // (scalars, opaquely: the VGPR copies of values computed before the loop were held for the
+    // kernel's life and spilled to scratch)
+    const double inv_box = uniform_f64(1.0 / box);
+    uint32_t gate_q;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(gate_q) : "v"(com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box)));
     int32_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
 
     for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
         // `lane` is made opaque once per unit: without this LLVM hoists every lane-derived address
         // and shuffle index of the body out of the persistent loop and holds them in registers
-        // for the kernel's whole lifetime (180 VGPRs instead of 128)
+        // for the kernel's whole lifetime (180 VGPRs instead of 128).  (lane0 itself is spilled
+        // to scratch and reloaded once per unit, long before its use.  Computing the lane id
+        // anew per unit in asm instead -- no range information for the compiler -- ran 4 % slower.)
         int lane = lane0;
         asm volatile("" : "+v"(lane));
         int rl = unit, part = 0;
@@ -195,12 +215,12 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
                 } else {
                     const int d = lane - 9;
                     (d == 0 ? bv.comx : d == 1 ? bv.comy : bv.comz)[r * bv.mol_stride + pend] = pw;
-                    comq_store(bv, r, pend, d, pw);
+                    comq_store(bv, r, pend, d, pw, inv_box);
                 }
             }
             if (bv.quat) { // totProps.quat[i] = ei (main.jl:619)
-                const double q0 = __shfl(pw, 13, 64), q1 = __shfl(pw, 14, 64),
-                             q2 = __shfl(pw, 15, 64), q3 = __shfl(pw, 16, 64);
+                const double q0 = wave_pick(pw, 13), q1 = wave_pick(pw, 14),
+                             q2 = wave_pick(pw, 15), q3 = wave_pick(pw, 16);
                 if (part == 0 && lane >= 13 && lane < 17)
                     quat_commit(bv, r, pend, lane - 13, pw, q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3 > 0.25);
             }
@@ -210,7 +230,17 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
         // (expanded where they are used: as variables they would be live across the whole unit)
 #define WV_CQ_BASE (bv.comq + (int64_t)r * 3 * bv.cq_stride)
 #define WV_PART_DST (out + (int64_t)r * n_parts + part)
+#define WV_ZERO opaque_f64(0.0)
+#define WV_SUBST SUBST
+    // (n_parts == 1: every unit has the reciprocal part, and the commit's stores, issued before the
+    // phase tables were computed, have mostly landed when those are done)
+#define WV_AFTER_PHASE_TABLES                                                                    \
+    if (!SUBST && commit)                                                                        \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's commit is in memory */
 #include "mmc_wave_unit.inc"
+#undef WV_AFTER_PHASE_TABLES
+#undef WV_SUBST
+#undef WV_ZERO
 #undef WV_CQ_BASE
 #undef WV_PART_DST
     }
@@ -231,7 +261,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
 // and 713 KB of HBM traffic per evaluation (every tile re-read by 12 workgroups) become ~1.3 k per
 // wave-unit and one gather per neighbour (profiles/README.md, round 2).
 struct TotalWaveShared {
-    alignas(16) double qtab[MMC_QQ_NINT * MMC_QQ_NCOEF];
+    alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     int32_t list[WV_WAVES][WV_LIST];
 };
 
@@ -251,7 +281,7 @@ __device__ __forceinline__ void total_wave_body(
     // wave walking a whole row; units_per_rep then counts those units
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += WV_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += WV_WAVES * 64)
         sm.qtab[k] = qq_tab[k];
     __syncthreads();
 
@@ -522,7 +552,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
     const int tid = threadIdx.x;
     int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int k = tid; k < MMC_QQ_NINT * MMC_QQ_NCOEF; k += blockDim.x)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += blockDim.x)
         sm.qtab[k] = qq_tab[k];
     __syncthreads();
 
