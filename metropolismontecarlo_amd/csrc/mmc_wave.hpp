@@ -354,23 +354,23 @@ __device__ __forceinline__ void total_wave_body(
                 auto pair_ab = [&](int ab, double ax, double ay, double az, double bx, double by,
                                    double bz) {
                     const double qq = fc.qq9[ab];
-                    const bool qneg = qq < 0;
+                    const bool qneg = (fc.qneg_mask >> ab) & 1; // uniform
                     const double px = vector1D_abs(ax, bx, bc), py = vector1D_abs(ay, by, bc),
                                  pz = vector1D_abs(az, bz, bc);
                     const double u0 = px * px + py * py + pz * pz;
-                    const bool c0 = u0 < pp.ovr;
-                    const unsigned long long cm0 = wave_ballot(c0) & gm0; // scalar mask arithmetic, see
-                    const bool ov0 = g0 && qneg && c0;                    // mmc_wave_unit.inc (ewalds.jl:359)
-                    const bool in0 = g0 && !ov0 && (u0 < pp.qq_slack_sq); // ewalds.jl:362
-                    double e0 = qq_table_eval_clamped(sm.qtab, u0);
+                    // scalar mask arithmetic and the table's row of zeros, as in mmc_wave_unit.inc
+                    // (ewalds.jl:359, :362)
+                    const unsigned long long cm0 = wave_ballot(u0 < pp.ovr) & gm0;
+                    const unsigned long long im0 = wave_ballot(u0 < pp.qq_slack_sq) & (qneg ? gm0 & ~cm0 : gm0);
+                    double e0 = qq_table_eval_lanes(sm.qtab, u0, im0);
                     if (qneg) {
                         ovm |= cm0;
                     } else if (cm0 != 0ULL) {
-                        if (u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
+                        if (((im0 >> lane) & 1) && u0 < MMC_QQ_UMIN) e0 = qq_pair_cold(u0, pp.kappa);
                     }
-                    a_q = fma(e0, in0 ? qq : 0.0, a_q);
+                    a_q = fma(e0, qq, a_q);
                     const double eps = fc.eps9[ab], sg = fc.sig9[ab];
-                    if (eps > 0.001) { // uniform (energy.jl:270)
+                    if ((fc.lj_mask >> ab) & 1) { // uniform (energy.jl:270: eps > 0.001)
                         if (l0 && u0 < pp.lj_slack_sq) {
                             const double s2 = sg * sg / u0;
                             const double s6 = s2 * s2 * s2;
