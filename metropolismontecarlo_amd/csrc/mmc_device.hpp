@@ -425,6 +425,16 @@ __device__ __forceinline__ cplx c_mul(cplx a, cplx b)
     r.im = a.re * b.im + a.im * b.re;
     return r;
 }
+// The same product with one rounding less per component (4 instructions instead of 6), for the
+// k-vector loop of the throughput kernel: no decision hangs on these values, and the sums stay
+// within a few 1e-16 relative of the unfused ones (the reference's tolerance is 1e-6).
+__device__ __forceinline__ cplx c_mul_fused(cplx a, cplx b)
+{
+    cplx r;
+    r.re = fma(a.re, b.re, -(a.im * b.im));
+    r.im = fma(a.re, b.im, a.im * b.re);
+    return r;
+}
 __device__ __forceinline__ cplx c_conj(cplx a) { cplx r = { a.re, -a.im }; return r; }
 __device__ __forceinline__ cplx c_rmul(double q, cplx a) { cplx r = { q * a.re, q * a.im }; return r; }
 
