@@ -42,6 +42,9 @@
 #ifndef WV_PF
 #define WV_PF 6      // 64-molecule blocks of the COM scan in flight ahead of the one being tested
 #endif
+// Bytes readable past the end of BatchView::comq: a scan prefetches WV_PF blocks ahead of the block
+// it tests, WV_PF blocks per trip, from the last molecule of the last replica at worst.
+#define MMC_CQ_PAD (4 * 64 * (2 * WV_PF + 2))
 #ifndef WV_TPF
 #define WV_TPF 3     // ... in k_total_wave, whose scans are 6 blocks long on average (4: spills at 96 VGPRs)
 #endif
