@@ -303,6 +303,11 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      number; same move distributions as the host generator, a different random
  *                      stream): only one flag byte per replica and step crosses PCIe and no host
  *                      mirror of the coordinates is kept.  Default 0.
+ *   "image_by_molecule" -1 (default) = the wave kernel takes the minimum image of an atom pair with
+ *                      the image of its molecule's centre of mass where that is the reference's
+ *                      vector1D bit for bit: moves made on the device (rigid), and
+ *                      gate + 2 r_mol < box / 2 (r_mol: the largest atom-to-centre distance of
+ *                      anything uploaded).  0 = never: the per-pair minimum image.
  *   "persistent"       the move server for small batches (device_moves = 1, kernel != 0, no
  *                      orientations, at most one replica per compute unit): mmc_batch_run /
  *                      mmc_batch_run_chains launch ONE kernel per call, a workgroup per replica

@@ -39,7 +39,7 @@
 #define MMC_QQ_DEG 9
 #define MMC_QQ_NCOEF (MMC_QQ_DEG + 1)
 #define MMC_QQ_NINT 160   // 10 octaves [2^-2, 2^8) x 16 sub-intervals
-#define MMC_QQ_NROW (MMC_QQ_NINT + 1) // ... and a row of zeros: where a masked-out evaluation lands
+#define MMC_QQ_NROW (MMC_QQ_NINT + 1) // ... after a row of zeros: where a masked-out evaluation lands
 #define MMC_QQ_TABLE_DOUBLES (MMC_QQ_NROW * MMC_QQ_NCOEF)
 #define MMC_QQ_UMIN 0.25
 #define MMC_QQ_UMAX 256.0    // the host selects this kernel only if r_cut^2 + 100 <= UMAX,
@@ -93,63 +93,65 @@ __device__ __forceinline__ double qq_horner(const double *c, double t)
     return acc;
 }
 
-// piece index and offset d = u - (centre of the piece) from the bits of u: the piece is the
-// exponent and the top 4 mantissa bits (0 at u = 0.25), its centre those bits with the next one set
-// -- three instructions, and the subtraction is exact.  The coefficients of a row are those of the
+// Row and offset d = u - (centre of the piece) from the bits of u: the piece is the exponent and
+// the top 4 mantissa bits (piece 0 at u = 0.25), its centre those bits with the next one set --
+// three instructions, and the subtraction is exact.  The coefficients of a row are those of the
 // polynomial in t = d / (half width) in [-1, 1), scaled by the powers of the half width: a power of
 // two, so Horner in d gives bit for bit what Horner in t gives on the unscaled coefficients
-// (k_build_qq_table).
-__device__ __forceinline__ double qq_piece(double u, int &idx)
+// (k_build_qq_table).  ROW 0 OF THE TABLE IS ALL ZEROS, piece i is row i + 1: a discarded
+// evaluation is sent to row 0 (one select on the row offset, the inline constant 0).
+__device__ __forceinline__ double qq_piece(double u, int &row)
 {
-    const unsigned lo = (unsigned)__double_as_longlong(u), hi = (unsigned)(__double_as_longlong(u) >> 32);
-    idx = (int)(hi >> 16) - 0x3FD0;
+    const unsigned hi = (unsigned)(__double_as_longlong(u) >> 32);
+    row = (int)(hi >> 16) - (0x3FD0 - 1);
     const unsigned chi = (hi & 0xFFFF0000u) | 0x8000u;
-    (void)lo;
     return u - __longlong_as_double((long long)((unsigned long long)chi << 32));
 }
 
-// f(u) = erfc(kappa*sqrt(u))/sqrt(u) on piece `idx`: Horner in t.
+// f(u) = erfc(kappa*sqrt(u))/sqrt(u) on the piece that holds u: Horner in d.
 __device__ __forceinline__ double qq_table_eval(const double *tab, double u)
 {
-    int idx;
-    const double t = qq_piece(u, idx);
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
+    int row;
+    const double t = qq_piece(u, row);
+    return qq_horner(tab + row * MMC_QQ_NCOEF, t);
 }
 
-// The same with the piece index clamped into the table: for predicated callers that evaluate
-// every lane and discard what lies outside [UMIN, UMAX) afterwards.
+// The same with the row clamped into the table: for predicated callers that evaluate every lane
+// and discard what lies outside [UMIN, UMAX) afterwards.
 __device__ __forceinline__ double qq_table_eval_clamped(const double *tab, double u)
 {
-    int idx;
-    const double t = qq_piece(u, idx);
-    idx = min(max(idx, 0), MMC_QQ_NINT - 1);
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
+    int row;
+    const double t = qq_piece(u, row);
+    row = min(max(row, 1), MMC_QQ_NINT);
+    return qq_horner(tab + row * MMC_QQ_NCOEF, t);
+}
+
+// ... with the discarding done by the table: a lane with keep == false evaluates the row of zeros,
+// so the caller adds e * (q_a q_b) unconditionally -- e is +-0 there, and x + 0 * q == x bit for
+// bit.  The caller guarantees u < UMAX where keep holds (the host selects these kernels only if
+// the cutoffs lie inside the table); below UMIN the row saturates at 0 or 1 and the caller's
+// series takes over.
+__device__ __forceinline__ double qq_table_eval_masked(const double *tab, double u, bool keep)
+{
+    int row;
+    const double t = qq_piece(u, row);
+    row = keep ? min(max(row, 0), MMC_QQ_NINT) : 0;
+    return qq_horner(tab + row * MMC_QQ_NCOEF, t);
 }
 
 // (keep as a lane mask in an SGPR pair, the way the wave kernels hold their gates: the select reads
-// it directly.  4.0f as a high word is 2^9 <= u < 2^10: beyond the table, finite.)
+// it directly.  Three instructions from the high word of u to the row's byte offset.)
 __device__ __forceinline__ double qq_table_eval_lanes(const double *tab, double u, unsigned long long keep)
 {
-    const unsigned lo = (unsigned)__double_as_longlong(u);
-    unsigned hi = (unsigned)(__double_as_longlong(u) >> 32);
-    asm("v_cndmask_b32_e64 %0, 4.0, %1, %2" : "=v"(hi) : "v"(hi), "s"(keep));
-    int idx;
-    const double t = qq_piece(__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), idx);
-    idx = min(max(idx, 0), MMC_QQ_NINT); // row NINT: zeros
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
-}
-
-// ... and with the discarding done by the table: a lane with keep == false evaluates the row of
-// zeros (one v_cndmask on the high word of u instead of a 64-bit select of the result), so the
-// caller adds e * (q_a q_b) unconditionally -- e is +-0 there, and x + 0 * q == x bit for bit.
-__device__ __forceinline__ double qq_table_eval_masked(const double *tab, double u, bool keep)
-{
-    const unsigned lo = (unsigned)__double_as_longlong(u);
-    const unsigned hi = keep ? (unsigned)(__double_as_longlong(u) >> 32) : 0x7FE00000u; // finite: 0 * d stays 0
-    int idx;
-    const double t = qq_piece(__longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)), idx);
-    idx = min(max(idx, 0), MMC_QQ_NINT); // row NINT: zeros
-    return qq_horner(tab + idx * MMC_QQ_NCOEF, t);
+    const unsigned hi = (unsigned)(__double_as_longlong(u) >> 32);
+    const unsigned chi = (hi & 0xFFFF0000u) | 0x8000u;
+    const double t = u - __longlong_as_double((long long)((unsigned long long)chi << 32));
+    unsigned row; // the high half of hi minus (0x3FD0 - 1), saturating at 0: one SDWA subtraction
+    asm("v_sub_u32_sdwa %0, %1, %2 clamp dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD"
+        : "=v"(row) : "v"(hi), "s"(0x3FD0u - 1u));
+    unsigned off = __umul24(row, (unsigned)(MMC_QQ_NCOEF * sizeof(double)));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(off) : "v"(off), "s"(keep));
+    return qq_horner(reinterpret_cast<const double *>(reinterpret_cast<const char *>(tab) + off), t);
 }
 
 // u < UMIN happens only for like charges closer than 0.5 A (opposite charges that close are
@@ -202,9 +204,9 @@ __global__ void k_build_qq_table(double kappa, double *tab)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= MMC_QQ_NROW)
         return;
-    if (idx == MMC_QQ_NINT) { // the row of zeros (qq_table_eval_masked)
+    if (idx == MMC_QQ_NINT) { // row 0: zeros (qq_table_eval_masked)
         for (int j = 0; j < MMC_QQ_NCOEF; j++)
-            tab[idx * MMC_QQ_NCOEF + j] = 0.0;
+            tab[j] = 0.0;
         return;
     }
     const int e = idx / 16 - 2, k = idx % 16;
@@ -242,7 +244,7 @@ __global__ void k_build_qq_table(double kappa, double *tab)
     }
     // Horner runs in d = u - uc = t * uh, uh = 2^(e - 5): the scaling is exact
     for (int j = 0; j < N; j++)
-        tab[idx * N + j] = ldexp(m[j], -j * (e - 5));
+        tab[(idx + 1) * N + j] = ldexp(m[j], -j * (e - 5));
 }
 
 // Evaluate the erfc(kappa r)/r approximation at arbitrary r^2 (accuracy tests, mmc_batch_qq_table).

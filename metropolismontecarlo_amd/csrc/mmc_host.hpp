@@ -49,6 +49,12 @@ struct DeviceSystem {
     // fast paths (mmc_fast.hpp, mmc_total.hpp): systems whose molecules are all copies of one
     // 3-atom molecule get per-molecule records, launch constants and the erfc table
     bool homogeneous = false;
+    // largest distance of an atom from its molecule's centre of mass over everything uploaded
+    // (rigid moves keep it); +inf once unknown.  Decides whether an atom pair's minimum image may
+    // be taken with its molecule's (WV_IMG, mmc_wave_unit.inc).
+    double r_mol_max = 0.0;
+    void note_shape(const double *com, const double *coords); // one replica's host arrays
+    bool image_by_molecule(double gate_sq) const;
     double *rec = nullptr;    // [R][n_mol][MMC_RSTRIDE], only when homogeneous
     FastConsts fc{};          // launch constants of the fast kernels
     double *qq_tab = nullptr; // [MMC_QQ_NINT][MMC_QQ_NCOEF] for the prepared kappa

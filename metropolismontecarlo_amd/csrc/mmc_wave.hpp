@@ -133,7 +133,9 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
 // SUBST = false (launches with n_parts == 1 only): the wave that writes a pending commit to memory
 // is the only reader of that replica in the launch -- it waits for its own stores (same compute
 // unit, same L1) instead of substituting the pending words in every gather and scan block.
-template <bool SUBST>
+// IMG = true: the minimum image of an atom pair from the image of its molecule (WV_IMG in
+// mmc_wave_unit.inc; the launch site checks the condition).
+template <bool SUBST, bool IMG>
 __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
 #define WV_PART_DST (out + (int64_t)r * n_parts + part)
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
+#define WV_IMG IMG
     // (n_parts == 1: every unit has the reciprocal part, and the commit's stores, issued before the
     // phase tables were computed, have mostly landed when those are done)
 #define WV_AFTER_PHASE_TABLES                                                                    \
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* this wave's commit is in memory */
 #include "mmc_wave_unit.inc"
 #undef WV_AFTER_PHASE_TABLES
+#undef WV_IMG
 #undef WV_SUBST
 #undef WV_ZERO
 #undef WV_CQ_BASE
