@@ -110,7 +110,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
     const double inv_box = 1.0 / box;
     const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
-    int32_t *const list = sm.list[wv];
+    wv_list_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
 
     const int r = 0;

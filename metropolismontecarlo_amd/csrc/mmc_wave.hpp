@@ -34,7 +34,10 @@
 #define WV_WAVES 4   // waves (= units in flight) per workgroup
 #endif
 #ifndef WV_OCC
-#define WV_OCC 4     // waves per SIMD k_move_eval_wave is compiled for
+#define WV_OCC 5     // waves per SIMD k_move_eval_wave is compiled for: 96 VGPRs, and 31 KB of LDS per
+#endif               // workgroup of four waves (five workgroups per compute unit)
+#ifndef WV_MWAVES
+#define WV_MWAVES WV_WAVES // waves per workgroup of k_move_eval_wave (they share one copy of the erfc table)
 #endif
 #ifndef WV_LIST
 #define WV_LIST 640  // neighbour-list slots per wave; the scan empties it when fewer than 64 WV_PF are free
@@ -49,10 +52,14 @@
 #define WV_TPF 3     // ... in k_total_wave, whose scans are 6 blocks long on average (4: spills at 96 VGPRs)
 #endif
 
+// Neighbour lists hold 16-bit molecule indices (half the LDS: with it five workgroups fit a compute
+// unit); the host takes these kernels for at most MMC_WAVE_MAX_MOL molecules.
+typedef uint16_t wv_list_t;
+#define MMC_WAVE_MAX_MOL 65535
 template <int NW> struct WaveSharedT {
     alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
     cplx ptab[NW][2][3][3][MMC_NKTAB]; // phase tables of the 3 moved atoms, old and new
-    int32_t list[NW][WV_LIST];
+    wv_list_t list[NW][WV_LIST];
     alignas(16) double pvw[NW][12];    // pending commit of the unit's replica, record layout
     alignas(16) double outw[NW][8];    // the PartOut being assembled
 };
@@ -136,17 +143,17 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
 // IMG = true: the minimum image of an atom pair from the image of its molecule (WV_IMG in
 // mmc_wave_unit.inc; the launch site checks the condition).
 template <bool SUBST, bool IMG>
-__global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
+__global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(WV_OCC, WV_OCC))) void k_move_eval_wave(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
     const MoveRec *__restrict__ prev, PartOut *out, int n_parts, PairParams pp, int r_base,
     int n_units, const uint8_t *__restrict__ flagv, unsigned stamp)
 {
-    __shared__ __align__(16) WaveShared sm;
+    __shared__ __align__(16) WaveSharedT<WV_MWAVES> sm;
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += WV_WAVES * 64)
+    for (int k = tid; k < MMC_QQ_TABLE_DOUBLES; k += WV_MWAVES * 64)
         sm.qtab[k] = qq_tab[k];
     __syncthreads(); // the only workgroup barrier: from here on the waves are independent
 
@@ -162,10 +169,10 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
     const double inv_box = uniform_f64(1.0 / box);
     uint32_t gate_q;
     asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(gate_q) : "v"(com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box)));
-    int32_t *const list = sm.list[wv];
+    wv_list_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
 
-    for (int unit = blockIdx.x * WV_WAVES + wv; unit < n_units; unit += gridDim.x * WV_WAVES) {
+    for (int unit = blockIdx.x * WV_MWAVES + wv; unit < n_units; unit += gridDim.x * WV_MWAVES) {
         // `lane` is made opaque once per unit: without this LLVM hoists every lane-derived address
         // and shuffle index of the body out of the persistent loop and holds them in registers
         // for the kernel's whole lifetime (180 VGPRs instead of 128).  (lane0 itself is spilled
@@ -238,6 +245,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
 #define WV_IMG IMG
+#define WV_PASSES 2 // (105-111 VGPRs unconstrained instead of 137-151: what makes WV_OCC = 5 possible)
     // (n_parts == 1: every unit has the reciprocal part, and the commit's stores, issued before the
     // phase tables were computed, have mostly landed when those are done)
 #define WV_AFTER_PHASE_TABLES                                                                    \
@@ -246,6 +254,7 @@ __global__ __launch_bounds__(WV_WAVES * 64, WV_OCC) void k_move_eval_wave(
 #include "mmc_wave_unit.inc"
 #undef WV_AFTER_PHASE_TABLES
 #undef WV_IMG
+#undef WV_PASSES
 #undef WV_SUBST
 #undef WV_ZERO
 #undef WV_CQ_BASE
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
     const bool same_gate = pp.lj_gate_sq == pp.qq_gate_sq;
     const double inv_box = 1.0 / box;
     const uint32_t gate_q = com_quant_gate(fmax(pp.lj_gate_sq, pp.qq_gate_sq), box);
-    int32_t *const list = sm.list[wv];
+    wv_list_t *const list = sm.list[wv];
     const double *const pvw = sm.pvw[wv];
     double *const mvw = mvw_all[wv];
 
