@@ -98,6 +98,7 @@ __device__ __forceinline__ void potential_finish(const BatchView &bv, const PotO
     }
 }
 
+template <bool IMG>
 __global__ __launch_bounds__(MMC_BLOCK) void k_potential_one(
     BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
     PairParams pp, RecipOrder order, PotOneArgs a)
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_potential_one(
 
     if ((int)blockIdx.x < a.pair_wgs) {
         // ---- pair part: units blockIdx.x * 4 + wave, ... (paired = 0: one molecule per unit) ----
-        total_wave_body<true>(sm, bv, rec, qq_tab, fc, pp, a.tparts, a.n_units, a.n_units, 0,
+        total_wave_body<true, IMG>(sm, bv, rec, qq_tab, fc, pp, a.tparts, a.n_units, a.n_units, 0,
                               (int)blockIdx.x, a.pair_wgs, a.j_chunk);
     } else {
         // ---- reciprocal part: column ci, atom chunk cz ----

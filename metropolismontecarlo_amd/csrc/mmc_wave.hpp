@@ -287,7 +287,9 @@ struct TotalWaveShared {
 // COHERENT: the unit partials are written with device-scope stores (they bypass the non-coherent
 // part of the XCD's L2), for a reader in the SAME launch on another XCD (k_potential_one's last
 // workgroup) -- a release fence instead would write back the whole L2 once per workgroup.
-template <bool COHERENT>
+// IMG: the minimum image of an atom pair from its molecule's (as WV_IMG in mmc_wave_unit.inc: bit
+// for bit vector1D where gate + 2 r_mol < box / 2, which the host checks).
+template <bool COHERENT, bool IMG>
 __device__ __forceinline__ void total_wave_body(
     TotalWaveShared &sm, const BatchView &bv, const double *__restrict__ rec,
     const double *__restrict__ qq_tab, const FastConsts &fc, const PairParams &pp, TotalPart *out,
@@ -361,8 +363,20 @@ __device__ __forceinline__ void total_wave_body(
                 };
                 const double ccx = mine(9), ccy = mine(10), ccz = mine(11);
                 // the gate, exactly (energy.jl:248-254, ewalds.jl:334-340)
-                const double x0 = vector1D_abs(ccx, t[9], bc), y0 = vector1D_abs(ccy, t[10], bc),
-                             z0 = vector1D_abs(ccz, t[11], bc);
+                double m[3] = { 0, 0, 0 }; // (IMG) the image of this neighbour's molecule: 0 or +-1 per axis
+                auto min1 = [&](int d, double a, double b) {
+                    if constexpr (IMG)
+                        return fma(m[d], bc.neg, b - a); // == vector1D(a, b, bc), signed
+                    else
+                        return vector1D_abs(a, b, bc);
+                };
+                if constexpr (IMG) {
+                    const double dx = t[9] - ccx, dy = t[10] - ccy, dz = t[11] - ccz;
+                    m[0] = (fabs(dx) < bc.half) ? 0.0 : copysign(1.0, dx);
+                    m[1] = (fabs(dy) < bc.half) ? 0.0 : copysign(1.0, dy);
+                    m[2] = (fabs(dz) < bc.half) ? 0.0 : copysign(1.0, dz);
+                }
+                const double x0 = min1(0, ccx, t[9]), y0 = min1(1, ccy, t[10]), z0 = min1(2, ccz, t[11]);
                 const double c0 = x0 * x0 + y0 * y0 + z0 * z0;
                 const bool g0 = act && (c0 < pp.qq_gate_sq);
                 const bool l0 = same_gate ? g0 : (act && (c0 < pp.lj_gate_sq));
@@ -371,8 +385,7 @@ __device__ __forceinline__ void total_wave_body(
                                    double bz) {
                     const double qq = fc.qq9[ab];
                     const bool qneg = (fc.qneg_mask >> ab) & 1; // uniform
-                    const double px = vector1D_abs(ax, bx, bc), py = vector1D_abs(ay, by, bc),
-                                 pz = vector1D_abs(az, bz, bc);
+                    const double px = min1(0, ax, bx), py = min1(1, ay, by), pz = min1(2, az, bz);
                     const double u0 = px * px + py * py + pz * pz;
                     // scalar mask arithmetic and the table's row of zeros, as in mmc_wave_unit.inc
                     // (ewalds.jl:359, :362)
@@ -392,12 +405,12 @@ __device__ __forceinline__ void total_wave_body(
                             const double s6 = s2 * s2 * s2;
                             const double s12 = s6 * s6;
                             const double virab = eps * (2.0 * s12 - s6);
-                            const double f0 = vector1D(ax, bx, bc) * virab * s2,
-                                         f1 = vector1D(ay, by, bc) * virab * s2,
-                                         f2 = vector1D(az, bz, bc) * virab * s2;
+                            const double f0 = (IMG ? px : vector1D(ax, bx, bc)) * virab * s2,
+                                         f1 = (IMG ? py : vector1D(ay, by, bc)) * virab * s2,
+                                         f2 = (IMG ? pz : vector1D(az, bz, bc)) * virab * s2;
                             a_lj += eps * (s12 - s6);
-                            a_v += vector1D(ccx, t[9], bc) * f0 + vector1D(ccy, t[10], bc) * f1
-                                   + vector1D(ccz, t[11], bc) * f2;
+                            a_v += (IMG ? x0 : vector1D(ccx, t[9], bc)) * f0 + (IMG ? y0 : vector1D(ccy, t[10], bc)) * f1
+                                   + (IMG ? z0 : vector1D(ccz, t[11], bc)) * f2;
                         }
                     }
                 };
@@ -481,12 +494,13 @@ __device__ __forceinline__ void total_wave_body(
     }
 }
 
+template <bool IMG>
 __global__ __launch_bounds__(WV_WAVES * 64, WV_TOTAL_WAVES_PER_SIMD) void k_total_wave(
     BatchView bv, const double *__restrict__ rec, const double *__restrict__ qq_tab, FastConsts fc,
     PairParams pp, TotalPart *out, int units_per_rep, int n_units, int paired)
 {
     __shared__ __align__(16) TotalWaveShared sm;
-    total_wave_body<false>(sm, bv, rec, qq_tab, fc, pp, out, units_per_rep, n_units, paired,
+    total_wave_body<false, IMG>(sm, bv, rec, qq_tab, fc, pp, out, units_per_rep, n_units, paired,
                            (int)blockIdx.x, (int)gridDim.x);
 }
 
