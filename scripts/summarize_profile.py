@@ -78,8 +78,9 @@ if wc and "SQ_ACTIVE_INST_VALU" in pmc and w:
     # SQ_WAVE_CYCLES sums the resident waves' cycles; the vector pipe of a SIMD serves all of its
     # waves, so its busy share is issue cycles x waves per SIMD / wave cycles
     extras["valu_busy_frac"] = pmc["SQ_ACTIVE_INST_VALU"]["per_dispatch"] * waves_per_simd / wc
-    # (SQ_WAVE_CYCLES / SIMDs / duration: the shader clock the counters imply while the kernel runs)
-    extras["clock_ghz"] = wc / n_simd / (trace["avg_us"] * 1e3)
+    # (SQ_WAVE_CYCLES counts quad-cycles summed over the resident waves: x 4 / waves / duration is
+    # the shader clock the counters imply while the kernel runs)
+    extras["clock_ghz"] = wc * 4.0 / (n_simd * waves_per_simd) / (trace["avg_us"] * 1e3)
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     hbm = (2 * pmc["FETCH_SIZE"]["per_dispatch"] + pmc["WRITE_SIZE"]["per_dispatch"]) * 1024
     extras["hbm_traffic_gbs"] = hbm / (trace["avg_us"] * 1e-6) / 1e9
