@@ -756,6 +756,21 @@ def _dense_water(n_mol, seed=5):
                 sig=a4["sig"], box=float(box))
 
 
+def test_table_kernels_are_refused_beyond_16_bit_molecule_indices():
+    """The wave kernels keep neighbour lists of 16-bit molecule indices: a system of more than 65535
+    molecules gets the generic kernel, and asking for another one is an error, not a wrong answer."""
+    from metropolismontecarlo_amd import structs, _lib
+    from metropolismontecarlo_amd.device import Batch
+    a = _dense_water(65600)
+    with Batch(1, a["com"], a["coords"], a["atype"], a["charge"], a["eps"], a["sig"], a["box"],
+               5.6 / a["box"], structs.factor, 10.0, 10.0) as b:
+        for k in (1, 2, 3, 4):
+            with pytest.raises(_lib.MMCError) as e:
+                b.set_option("kernel", k)
+            assert "65535" in str(e.value)
+        b.set_option("kernel", 0)
+
+
 @pytest.mark.parametrize("kernel,parts", [(2, 1), (1, 1), (2, 3), (1, 2)])
 def test_long_neighbour_lists_and_many_molecules(kernel, parts, orc):
     """1700 molecules with a 12.4 A cutoff: ~265 neighbours inside the gate, i.e. more than one
