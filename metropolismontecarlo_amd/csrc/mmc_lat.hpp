@@ -128,7 +128,7 @@ __host__ __device__ inline bool lat_applies(int n_parts, int n_mol, int nkv)
             } else {                                                                               \
                 const int d_ = lane - 9;                                                           \
                 (d_ == 0 ? bv.comx : d_ == 1 ? bv.comy : bv.comz)[(r) * bv.mol_stride + (pm)] = (val); \
-                comq_store(bv, (r), (pm), d_, (val));                                              \
+                comq_store(bv, (r), (pm), d_, (val), inv_box);                                     \
             }                                                                                      \
         }                                                                                          \
     } while (0)
@@ -222,6 +222,21 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_eval_lat(
         lat_store_combined<false>(ls, out + (int64_t)r * (n_parts / LAT_WAVES) + g, lane, stamp);
 }
 
+// Diagnostic build (-DLAT_PROFILE, scripts/dev_lat_profile.py): every wave of replica 0 sums the
+// 10 ns ticks it spends per phase of a step -- waiting for the word, commit, unit body, barrier +
+// record, next proposal -- read back with mmc_debug_lat_profile.  Compiled out of the product.
+#ifdef LAT_PROFILE
+__device__ unsigned long long g_lat_prof[64][8];
+#define LAT_TICK(k)                                                                              \
+    do {                                                                                         \
+        const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();                       \
+        lat_acc[k] += t_now - lat_t;                                                             \
+        lat_t = t_now;                                                                           \
+    } while (0)
+#else
+#define LAT_TICK(k)
+#endif
+
 // =================================================================================================
 // k_move_server_lat: the persistent move server, G workgroups per replica.
 // grid = R * G (workgroup b: replica b / G, group b % G), block 256.  Protocol of
@@ -257,8 +272,9 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
 
     // the move record of step s (lane t = word t), drawn from the chosen molecule's record in
     // global memory -- which this workgroup keeps current itself (LAT_COMMIT_GLOBAL below)
-    auto make_proposal = [&](int64_t s) {
-        const int i0p = (int)(s % n_mol);
+    // (the molecule of a step is step mod n_mol, main.jl:490: kept as running 32-bit counters -- a
+    // 64-bit modulo is ~150 scalar instructions, and there were three of them per step)
+    auto make_proposal = [&](int64_t s, int i0p) {
         double cur = 0.0;
         if (lane < MMC_REC)
             cur = myrec[(int64_t)i0p * MMC_RSTRIDE + lane];
@@ -293,7 +309,11 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
         return wnew;
     };
 
-    double w = make_proposal(0), pw = 0.0;
+    int mol_cur = 0; // step mod n_mol
+    double w = make_proposal(0, 0), pw = 0.0;
+#ifdef LAT_PROFILE
+    unsigned long long lat_acc[6] = { 0, 0, 0, 0, 0, 0 }, lat_t = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int64_t step = 0;; step++) {
         asm volatile("" : "+v"(lane)); // keep lane-derived values out of LICM (see k_move_eval_wave)
         // ---- wave 0: the host's word of this step (bounded wait), published through LDS ----
@@ -325,6 +345,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
                 ls.ctl = c;
         }
         __syncthreads(); // the word is published (and every wave is done with the previous step's LDS)
+        LAT_TICK(0); // waited for the word
         const unsigned long long c =
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ls.ctl >> 32)) << 32)
             | (unsigned)__builtin_amdgcn_readfirstlane((int)ls.ctl);
@@ -334,20 +355,28 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
         const unsigned stamp = (unsigned)((c >> 8) & MMC_STAMP_MASK);
         // the previous step was accepted (main.jl:598-621): every wave refreshes its own copy, one
         // wave per workgroup writes the global copies (this workgroup's L2 then holds them)
-        if ((flags & SRV_ACCEPT) && step > 0) {
-            const int pm = (int)((step - 1) % n_mol);
-            const double val = __shfl(pw, lane < 9 ? MV_AT_NEW + lane : MV_COM_NEW + (lane < 12 ? lane - 9 : 0), 64);
-            LAT_REFRESH(pm, val);
-            if (wv == 0)
-                LAT_COMMIT_GLOBAL(r, pm, val, myrec);
+        // (the global copies are written after this step's record has left: only later proposals
+        // and whoever reads the state after the run need them)
+        const bool commit_prev = (flags & SRV_ACCEPT) && step > 0;
+        const int pm = mol_cur == 0 ? n_mol - 1 : mol_cur - 1; // (step - 1) mod n_mol
+        double commit_val = 0.0;
+        if (commit_prev) {
+            commit_val = __shfl(pw, lane < 9 ? MV_AT_NEW + lane : MV_COM_NEW + (lane < 12 ? lane - 9 : 0), 64);
+            LAT_REFRESH(pm, commit_val);
         }
+        // (... at once where no record follows -- a quit -- and where the next proposal reads the
+        // very molecule: two molecules, every wave reads the record for itself after the barrier)
+        const bool commit_early = (flags & SRV_QUIT) || n_mol <= 2;
+        if (commit_prev && wv == 0 && commit_early)
+            LAT_COMMIT_GLOBAL(r, pm, commit_val, myrec);
         if (flags & SRV_QUIT)
             break;
         if (flags & SRV_STEPS)
             sz = load_steps();
         if (n_mol == 1 || (flags & SRV_STEPS)) // the speculative proposal is out of date
-            w = make_proposal(step);
-        const int i0 = (int)(step % n_mol);
+            w = make_proposal(step, mol_cur);
+        LAT_TICK(1); // commit of the previous step
+        const int i0 = mol_cur;
         const int scur = (flags & SRV_SCUR) ? 1 : 0;
 #define WV_NS 2
 #define WV_S_BASE s_buf(bv, r, scur)
@@ -356,15 +385,27 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
 #undef WV_S_DST
 #undef WV_S_BASE
 #undef WV_NS
+        LAT_TICK(2); // unit body
         __syncthreads(); // every wave's sums are in ls.outw
-        if (wv == 0)
+        LAT_TICK(3); // waited for the slowest wave
+        if (wv == 0) {
             lat_store_combined<true>(ls, part_dst, lane, stamp);
+            if (commit_prev && !commit_early)
+                LAT_COMMIT_GLOBAL(r, pm, commit_val, myrec);
+        }
+        LAT_TICK(4); // record
         pw = w;
         if (n_mol > 1) {
-            // while the host decides this step.  The record of the next molecule must be read
-            // AFTER this workgroup's own commit stores of this step's control word: they were
-            // issued above, by wave 0, before the barrier
-            w = make_proposal(step + 1);
+            // while the host decides this step.  (The record read here is another molecule's than
+            // the one wave 0 has just committed, unless there are only two: see commit_early.)
+            w = make_proposal(step + 1, mol_cur + 1 == n_mol ? 0 : mol_cur + 1);
         }
+        LAT_TICK(5); // next proposal
+        mol_cur = mol_cur + 1 == n_mol ? 0 : mol_cur + 1;
     }
+#ifdef LAT_PROFILE
+    if (r == 0 && lane == 0)
+        for (int k = 0; k < 6; k++)
+            g_lat_prof[g * LAT_WAVES + wv][k] = lat_acc[k];
+#endif
 }

@@ -620,8 +620,9 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
 
     // the move record of step s as a lane-distributed register (lane t = word t), drawn from the
     // chosen molecule's record: k_propose's rigid generator
-    auto make_proposal = [&](int64_t s) {
-        const int i0p = (int)(s % n_mol);
+    // (the molecule of a step is step mod n_mol, main.jl:490: kept as running 32-bit counters -- a
+    // 64-bit modulo is ~150 scalar instructions, and there were three of them per step)
+    auto make_proposal = [&](int64_t s, int i0p) {
         double cur = 0.0;
         if (lane < MMC_REC)
             cur = myrec[(int64_t)i0p * MMC_RSTRIDE + lane];
@@ -656,7 +657,8 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
         return wnew;
     };
 
-    double w = make_proposal(0), pw = 0.0;
+    int mol_cur = 0; // step mod n_mol
+    double w = make_proposal(0, 0), pw = 0.0;
 #ifdef SRV_PROFILE
     unsigned long long pt[6] = {0, 0, 0, 0, 0, 0}, p0, p1, p2, p3, p4, p5;
 #define SRV_T(x) x = __builtin_amdgcn_s_memrealtime()
@@ -695,7 +697,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
             SRV_T(p1);
             // the previous step was accepted: commit it (main.jl:598-621)
             if (c != SRV_GAVE_UP && (c & SRV_ACCEPT) && step > 0) {
-                const int pm = (int)((step - 1) % n_mol);
+                const int pm = mol_cur == 0 ? n_mol - 1 : mol_cur - 1; // (step - 1) mod n_mol
                 int word = -1; // record word this lane's piece of the previous proposal goes to
                 if (lane >= MV_AT_NEW && lane < MV_AT_NEW + 9) word = lane - MV_AT_NEW;
                 else if (lane >= MV_COM_NEW && lane < MV_COM_NEW + 3) word = 9 + lane - MV_COM_NEW;
@@ -732,8 +734,8 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
         if (flags & SRV_STEPS)
             sz = load_steps();
         if (n_mol == 1 || (flags & SRV_STEPS)) // the speculative proposal is out of date
-            w = make_proposal(step);
-        const int i0 = (int)(step % n_mol);
+            w = make_proposal(step, mol_cur);
+        const int i0 = mol_cur;
         const int scur = (flags & SRV_SCUR) ? 1 : 0;
         const int pend = -1;
 #define WV_UNIT_NO_STORE
@@ -763,10 +765,11 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_move_server_wave(
         SRV_T(p5);
         pw = w;
         if (n_mol > 1)
-            w = make_proposal(step + 1); // while the host decides this step
+            w = make_proposal(step + 1, mol_cur + 1 == n_mol ? 0 : mol_cur + 1); // while the host decides this step
 #ifdef SRV_PROFILE
         pt[0] += p1 - p0; pt[1] += p2 - p1; pt[2] += p3 - p2; pt[3] += p4 - p3; pt[4] += p5 - p4;
         pt[5] += __builtin_amdgcn_s_memrealtime() - p5;
 #endif
+        mol_cur = mol_cur + 1 == n_mol ? 0 : mol_cur + 1;
     }
 }
