@@ -221,6 +221,39 @@ __device__ __forceinline__ double wave_sum_rows(double v)
     return ((r[0] + r[1]) + r[2]) + r[3];
 }
 
+// N such sums at once, step by step across all of them: the six sums of a unit are independent
+// chains of ~15 dependent instructions each, and written one after the other that is how they were
+// scheduled (0.47 us of a latency unit's 2.4); in lockstep they overlap.  Same operations, same
+// order within each sum: the same bits as wave_sum_rows.
+template <int N> __device__ __forceinline__ void wave_sum_rows_n(double (&v)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_row_shr_f64<1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_row_shr_f64<2>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_row_shr_f64<4>(v[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] += dpp_row_shr_f64<8>(v[k]);
+    double r[N][4];
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const long long b = __double_as_longlong(v[k]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)b, 16 * q + 15);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 16 * q + 15);
+            r[k][q] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = r[k][0] + r[k][1];
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = v[k] + r[k][2];
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = v[k] + r[k][3];
+}
+
 // Sum NV values over the 256-thread workgroup; thread 0 gets the totals in out[].
 // red: LDS scratch of NV * MMC_WAVES doubles.  Fixed order -> bitwise reproducible.
 template <int NV>

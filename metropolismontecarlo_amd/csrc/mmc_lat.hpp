@@ -313,6 +313,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
     double w = make_proposal(0, 0), pw = 0.0;
 #ifdef LAT_PROFILE
     unsigned long long lat_acc[6] = { 0, 0, 0, 0, 0, 0 }, lat_t = __builtin_amdgcn_s_memrealtime();
+    unsigned long long sub_acc[4] = { 0, 0, 0, 0 };
 #endif
     for (int64_t step = 0;; step++) {
         asm volatile("" : "+v"(lane)); // keep lane-derived values out of LICM (see k_move_eval_wave)
@@ -381,7 +382,19 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
 #define WV_NS 2
 #define WV_S_BASE s_buf(bv, r, scur)
 #define WV_S_DST s_buf(bv, r, scur ^ 1)
+#ifdef LAT_PROFILE
+        unsigned long long sub_t = __builtin_amdgcn_s_memrealtime();
+#define LAT_SUBTICK(k)                                                                           \
+    do {                                                                                         \
+        const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();                       \
+        sub_acc[k] += t_now - sub_t;                                                             \
+        sub_t = t_now;                                                                           \
+    } while (0)
+#endif
 #include "mmc_wave_lat.inc"
+#ifdef LAT_PROFILE
+#undef LAT_SUBTICK
+#endif
 #undef WV_S_DST
 #undef WV_S_BASE
 #undef WV_NS
@@ -407,5 +420,9 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_server_lat(
     if (r == 0 && lane == 0)
         for (int k = 0; k < 6; k++)
             g_lat_prof[g * LAT_WAVES + wv][k] = lat_acc[k];
+    if (r == 0 && lane == 0) { // two of the unit's sub-phases share the last two slots
+        g_lat_prof[g * LAT_WAVES + wv][6] = (sub_acc[0] + sub_acc[1]) | (sub_acc[2] << 32);
+        g_lat_prof[g * LAT_WAVES + wv][7] = sub_acc[3];
+    }
 #endif
 }

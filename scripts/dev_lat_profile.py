@@ -27,5 +27,8 @@ print("wave " + " ".join(f"{x:>10s}" for x in names) + "      sum (us per step)"
 for w in range(64):
     if buf[w].sum() == 0: continue
     v = buf[w, :6].astype(float) * 0.01 / n
-    print(f"{w:4d} " + " ".join(f"{x:10.2f}" for x in v) + f" {v.sum():10.2f}")
+    setup_scan = float(int(buf[w, 6]) & 0xffffffff) * 0.01 / n
+    rounds = float(int(buf[w, 6]) >> 32) * 0.01 / n
+    sums = float(buf[w, 7]) * 0.01 / n
+    print(f"{w:4d} " + " ".join(f"{x:10.2f}" for x in v) + f" {v.sum():10.2f}   unit: setup+scan {setup_scan:.2f} rounds {rounds:.2f} sums {sums:.2f}")
 b.close()
