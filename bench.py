@@ -651,6 +651,22 @@ def main():
                 if rf2:
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry
+            if R >= 4096 and args.streams == 0 and not res["server"]:
+                # The same workload with the two groups on TWO streams: their launches overlap (the
+                # start of one fills the tail of the other; no gap between launches), so a launch's
+                # own span no longer says what it costs -- which is why the headline line keeps one
+                # stream, where event time, trace time and step time add up.
+                a2 = argparse.Namespace(**{**vars(args), "streams": 2})
+                sh2 = dict(shape, steps=min(shape["steps"], 200), warmup=min(shape["warmup"], 20), prewarm=0)
+                r_ = measure_moves(R, a, a2, local_rank, g0, barrier, sh2)
+                out["two_streams"] = {
+                    "value": r_["st"]["moves"] / r_["elapsed"], "unit": "moves/s",
+                    "ms_per_step": 1e3 * r_["elapsed"] / sh2["steps"], "steps": sh2["steps"],
+                    "launch_span_us": (1e3 * r_["st"]["kernel_ms"] / r_["st"]["timed_launches"]
+                                       if r_["st"]["timed_launches"] else None),
+                    "energy_drift_rel": r_["drift"],
+                    "note": "launches of the two groups overlap: launch_span_us is the span of one "
+                            "launch sharing the GPU with the other, not its cost (ms_per_step / 2 is)"}
             out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
             out["call_surface"] = call_surface(a)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
