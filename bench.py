@@ -157,14 +157,19 @@ def server_lat_parts(R, n_mol):
     csrc/mmc_batch.inc), or 0 when it takes the one-workgroup server or none."""
     if R > 128:
         return 0
-    G = 4 if R <= 4 else 2
-    while G >= 2:
+    def applies(G):
         P = 4 * G
         nr = 3 if P >= 12 else 2
-        if -(-n_mol // (P - nr)) <= 128:
-            return P
+        return -(-n_mol // (P - nr)) <= 128
+    G = 4 if R <= 4 else 2
+    while G >= 2:
+        if applies(G):
+            return 4 * G
         G -= 1
-    return 0
+    G = (-(-n_mol // 128) + 3 + 3) // 4     # a large system: as many workgroups as it takes
+    while G <= 32 and not applies(G):
+        G += 1
+    return 4 * G if G <= 32 and R * G <= N_CUS else 0
 
 
 def shape_for(R, args):
@@ -342,6 +347,25 @@ def single_system_latency(a, local_rank):
                                             "energy_after_rejections_K": e_back,
                                             "host_round_trips": 0}
         ctx.close()
+        if nm == 10000:   # ... and the trial moves between two volume moves: one chain of this system
+            from metropolismontecarlo_amd.device import Batch
+            b = Batch(1, s["com"], s["coords"], s["atype"], s["charge"], s["eps"], s["sig"], s["box"],
+                      5.6 / s["box"], structs.factor, RCUT, RCUT, device=local_rank)
+            b.set_option("device_moves", 1)
+            e0 = b.potential_ewald(as_array=True)["energy"].copy()
+            e0, _ = b.run(300, TEMPERATURE, DR_MAX, DPHI_MAX, SEED, e0, n_groups=1, n_threads=1)
+            n_mv = 3000
+            t0 = time.perf_counter()
+            e1, st = b.run(n_mv, TEMPERATURE, DR_MAX, DPHI_MAX, SEED + 1, e0, n_groups=1, n_threads=1)
+            dt = time.perf_counter() - t0
+            e2 = b.potential_ewald(as_array=True)["energy"]
+            out["npt_trial_moves_10000"] = {
+                "us_per_move": 1e6 * dt / n_mv, "moves": n_mv,
+                "driver": "persistent move server" if st["server_steps"] else "one launch per step",
+                "workgroups_per_replica": server_lat_parts(1, nm) // 4,
+                "acceptance": (st["trans_accept"] + st["rot_accept"]) / max(st["moves"], 1),
+                "energy_drift_rel": float(np.abs(e1 - e2).max() / np.abs(e2).max())}
+            b.close()
     return out
 
 

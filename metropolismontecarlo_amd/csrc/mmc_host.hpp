@@ -35,7 +35,8 @@ void mmc_set_error(const char *fmt, ...);
             return st__;                                                                         \
     } while (0)
 
-#define MMC_MAX_PARTS 16 // result records (units) per trial move
+#define MMC_MAX_PARTS 32 // result records (units) per trial move
+static_assert(LAT_MAX_PARTS / LAT_WAVES <= MMC_MAX_PARTS, "one record per workgroup of the latency kernels");
 #define MMC_NK_STRIDE 352 // >= 337 k-vectors, 16-element aligned
 
 // Device state of R replicas of one system + Ewald tables.  R = 1 for a context.

@@ -19,6 +19,7 @@
 #define LAT_WAVES 4     // waves per workgroup (256 threads): one per SIMD
 #define LAT_MAXMOL 128  // molecules of a pair part: two 64-lane blocks of resident codes
 #define LAT_KIT 6       // k-iterations (64 vectors each) a reciprocal part may have: all 337 vectors
+#define LAT_MAX_PARTS 128 // waves per replica at most (32 workgroups: 125 pair parts x 128 = 16000 molecules)
 
 struct LatShared {
     alignas(16) double qtab[MMC_QQ_TABLE_DOUBLES];
@@ -48,7 +49,7 @@ __host__ __device__ inline LatPlan lat_plan(int n_parts, int n_mol, int nkv)
 // the latency kernels apply when every pair part's range fits a wave's resident storage
 __host__ __device__ inline bool lat_applies(int n_parts, int n_mol, int nkv)
 {
-    if (n_parts < 4 || n_parts % LAT_WAVES != 0 || n_parts > 16)
+    if (n_parts < 4 || n_parts % LAT_WAVES != 0 || n_parts > LAT_MAX_PARTS)
         return false;
     const LatPlan p = lat_plan(n_parts, n_mol, nkv);
     return p.plen <= LAT_MAXMOL && p.n_it <= LAT_KIT && p.np >= 1;

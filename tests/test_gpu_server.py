@@ -201,3 +201,34 @@ def test_server_wait_is_bounded():
         assert np.array_equal(e0, e)
         e1, st = b.run(10, 298.15, 0.3, 0.05, 3, e0, n_groups=1)
         assert st["moves"] == 20
+
+
+def test_latency_server_of_a_large_system():
+    """10 000 molecules (BASELINE configs[3]): more than four workgroups' resident storage holds, so the
+    server takes as many as it needs -- 21 workgroups, 84 parts -- and the host adds 21 records per
+    step.  Bit for bit the chain of k_move_eval_lat launched per step with the same parts; the
+    default shape (no part count given) is that server too."""
+    from metropolismontecarlo_amd import io as mio, structs
+    from metropolismontecarlo_amd.device import Batch
+    nm = 10000
+    box, com, coords = mio.cubic_lattice_water(nm, 0.033101144, "spce", seed=11234)
+    a4 = common.nist_arrays(4, "unwrapped")
+    atype = np.tile([1, 2, 2], nm)
+    charge = np.tile([mio.SPCE_Q_O, mio.SPCE_Q_H, mio.SPCE_Q_H], nm)
+    res = []
+    for persistent, parts in ((1, 84), (0, 84), (1, 0)):
+        with Batch(1, com, coords, atype, charge, a4["eps"], a4["sig"], box, 5.6 / box, structs.factor,
+                   10.0, 10.0) as b:
+            b.set_option("device_moves", 1)
+            b.set_option("persistent", persistent)
+            if parts:
+                b.set_option("kernel", 4)
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            e, st = b.run(120, 298.15, 0.3, 0.05, 23, e, n_groups=1, n_parts=parts)
+            assert st["torn_records"] == 0 and st["server_steps"] == (120 if persistent else 0)
+            e2 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e - e2).max() <= 1e-11 * np.abs(e2).max()
+            res.append((e.copy(), st["trans_accept"] + st["rot_accept"], state(b)))
+    assert res[0][1] > 20
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and res[0][1] == other[1] and same(res[0][2], other[2])
