@@ -42,6 +42,12 @@
 #define CS_RECIP 4u  // reciprocal part: S[s_dst] = S[s_base] + dS(old -> new), dE against S[s_base]
 #define CS_QUIT 8u
 #define CS_NEXT 16u  // the look-ahead workgroups evaluate molecule `mol2` (one state, its device record) as well
+// record slots of k_ctx_server_lat with G workgroups per role: results out[g], the look-ahead
+// workgroups' out[G + g], the S-mirror sums of workgroups with reciprocal waves out[2 G + g]
+#define CS_OUT_AHEAD(G, g) ((G) + (g))
+#define CS_OUT_SSUM(G, g) (2 * (G) + (g))
+#define CS_OUT_RECORDS (3 * MMC_CTX_MAX_WGS)
+#define MMC_CTX_MAX_WGS 32
 #define CS_IDLE_TICKS 100000000ULL // 1 s of the 100 MHz real-time counter
 
 // The command block: 64 words of 8 bytes = eight 64-byte lines; the LAST word of every line is a
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(SRV_WAVES * 64, 2) void k_ctx_server(
 // k_ctx_server_lat: the same protocol on the latency unit body (mmc_wave_lat.inc, mmc_lat.hpp):
 // G workgroups of four waves, each wave a part with its molecule range resident; one combined
 // record per workgroup (out[g]), and -- for commands with a reciprocal part -- the integrity sum of
-// the mirrored S_new of the workgroup's reciprocal waves in a second record (out[8 + g]).
+// the mirrored S_new of the workgroup's reciprocal waves in a second record (out[CS_OUT_SSUM(G, g)]).
 // =================================================================================================
 __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
         ls.qtab[k] = qq_tab[k];
     // workgroups [0, G): the command's evaluation; [G, 2 G) (when launched): LOOK-AHEAD -- the same
     // part plan, evaluating the molecule the host expects to be asked about next (CS_NEXT) in the
-    // state this command leaves behind.  Their records (out[4 + g]) are collected by the host
+    // state this command leaves behind.  Their records (out[CS_OUT_AHEAD(G, g)]) are collected by the host
     // when and if that call comes; nobody waits for them.
     const int G = n_parts / LAT_WAVES;
     const int r = 0, role = (int)blockIdx.x / G, g = (int)blockIdx.x - role * G;
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
             }
             __syncthreads();
             if (wv == 0)
-                lat_store_combined<true>(ls, out + 4 + g, lane, stamp);
+                lat_store_combined<true>(ls, out + CS_OUT_AHEAD(G, g), lane, stamp);
             continue;
         }
         const unsigned long long wmol = cw[CS_PHYS(CS_W_MOL)], wsb = cw[CS_PHYS(CS_W_SBUF)];
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_ctx_server_lat(
                 if (lane == 7)
                     ls.comb[7] = pack_ovl(0, 0, stamp, csum);
                 wave_sync();
-                store_part<true>(out + 8 + g, ls.comb, lane);
+                store_part<true>(out + CS_OUT_SSUM(G, g), ls.comb, lane);
                 wave_sync();
             }
         }
