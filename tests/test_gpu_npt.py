@@ -214,3 +214,35 @@ def test_npt_accept_reject_cycle_at_10000_molecules(orc):
         e, _, ov = ctx.ewald_short(77, RCUT)
         eo, _, ovo = orc.ewald_short(77, s2, orc.Ewald(5.6 / b2, 5, 27, b2), RCUT)
         assert ov == ovo and rel(e, eo) < TOL
+
+
+def test_context_server_of_a_large_system_equals_launch_per_evaluation():
+    """10 000 molecules: the context server takes 21 workgroups (plus 21 looking ahead); the same
+    trial moves with a launch per evaluation (option "server" = 0) give the same terms to 1e-12,
+    accepted and rejected moves mixed, and the structure factors agree at the end."""
+    a = water_lattice(10000, "spce")
+    rng_moves = np.random.default_rng(3).random((60, 3))
+    res = {}
+    for server in (1, 0):
+        with common.device_context(a) as ctx:
+            ctx.set_option("server", -1 if server else 0)
+            c, x = a["com"].copy(), a["coords"].copy()
+            out = []
+            for k in range(60):
+                i = (k * 167) % 10000 + 1
+                d = (rng_moves[k] - 0.5) * 0.3
+                cn, an = c[i - 1] + d, x[3 * (i - 1):3 * i] + d
+                du, ov = ctx.trial_move(i, cn, an, RCUT, RCUT)
+                out.append(du.copy())
+                if k % 3 and not ov:
+                    ctx.accept_move()
+                    c[i - 1] = cn
+                    x[3 * (i - 1):3 * i] = an
+                else:
+                    ctx.reject_move()
+            st = ctx.stats()
+            assert (st["cmds"] > 0) == bool(server)
+            res[server] = (np.array(out), ctx.get_sumqexp()[0].copy())
+    scale = np.abs(res[0][0]).max() + 1e4
+    assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * scale
+    assert np.abs(res[1][1] - res[0][1]).max() < 1e-11 * np.abs(res[0][1]).max()
