@@ -161,7 +161,7 @@ def server_lat_parts(R, n_mol):
         P = 4 * G
         nr = 3 if P >= 12 else 2
         return -(-n_mol // (P - nr)) <= 128
-    G = 4 if R <= 4 else 2
+    G = 4 if R <= 16 else 2
     while G >= 2:
         if applies(G):
             return 4 * G
