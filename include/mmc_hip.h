@@ -321,12 +321,13 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      -1 (default) = use it for up to 128 replicas when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
  *   "trace_steps"      test hook: see mmc_batch_get_trace
- *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 up to 4 replicas,
- *                      else 2, when every workgroup's molecule ranges fit its waves' resident
- *                      storage (at most 128 molecules per pair part) and R x workgroups does not
- *                      exceed the compute units; 0 = one workgroup per replica (k_move_server_wave);
- *                      2..4 = that many (k_move_server_lat: each workgroup polls the replica's
- *                      control word itself and keeps its own copy of its molecules)
+ *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 up to 16 replicas,
+ *                      else 2 -- or, for a system too large for that, as many as it takes for
+ *                      every pair wave to hold at most 128 molecules (10 000 molecules: 21) --
+ *                      while R x workgroups does not exceed the compute units; 0 = one workgroup
+ *                      per replica (k_move_server_wave); 2..32 = that many (k_move_server_lat: each
+ *                      workgroup polls the replica's control word itself and keeps its own copy
+ *                      of its molecules)
  *   "server_stall_ms"  test hook: the driver sleeps this long before posting the control words of
  *                      step 2 (the server's bounded wait must end the run with MMC_ERR_HIP)
  *   "server_seq_offset" test hook: the control words' sequence numbers (24 bits, compared modulo
