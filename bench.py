@@ -161,7 +161,7 @@ def server_lat_parts(R, n_mol):
         P = 4 * G
         nr = 3 if P >= 12 else 2
         return -(-n_mol // (P - nr)) <= 128
-    G = 4 if R <= 16 else 2
+    G = 4 if 4 * R <= N_CUS else 2
     while G >= 2:
         if applies(G):
             return 4 * G
@@ -179,8 +179,8 @@ def shape_for(R, args):
     small = R < 4096
     groups = args.groups if args.groups > 0 else (1 if R == 1 else 2)
     threads = args.threads
-    if small:
-        threads = min(threads, groups)
+    if small: # the move server steps every replica at its own pace: a thread per ~8 replicas
+        threads = max(1, min(threads, R // 8))
     steps = args.steps if args.steps is not None else (3000 if small else 600)
     warmup = args.warmup if args.warmup is not None else (300 if small else 60)
     zero_copy = args.zero_copy_moves if args.zero_copy_moves >= 0 else (1 if small else 0)
