@@ -155,7 +155,7 @@ def kernel_name(kernel_opt, moves_per_launch, parts):
 def server_lat_parts(R, n_mol):
     """Parts (waves) of the latency move server the library takes for R replicas (batch_lat_shape,
     csrc/mmc_batch.inc), or 0 when it takes the one-workgroup server or none."""
-    if R > 128:
+    if R > N_CUS:
         return 0
     def applies(G):
         P = 4 * G
@@ -192,7 +192,7 @@ def shape_for(R, args):
 def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, persistent=None):
     """One timed run of the native driver on a fresh batch of R replicas.  Returns the figures of
     this rank; the caller reduces over ranks.  `persistent`: the move server for small batches
-    (None = the --persistent flag; the library's default takes it up to 128 replicas)."""
+    (None = the --persistent flag; the library's default takes it up to one replica per compute unit)."""
     from metropolismontecarlo_amd import sharding, structs
     from metropolismontecarlo_amd.device import Batch
     box = a["box"]
@@ -514,7 +514,7 @@ def main():
     ap.add_argument("--device-moves", type=int, default=1,
                     help="1 = trial moves are drawn on the device (Philox), 0 = by the host driver")
     ap.add_argument("--persistent", type=int, default=-1,
-                    help="move server for small batches: -1 = library default (up to 128 replicas), "
+                    help="move server for small batches: -1 = library default (up to one replica per compute unit), "
                          "0 = a launch per step, 1 = insist")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)

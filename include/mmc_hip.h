@@ -318,7 +318,7 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      with n_parts = the server's waves (ceil(molecules / 64) + 1, at most 8 -- 5 for
  *                      a single replica -- or mmc_run_params.n_parts when > 1).  Every device-side wait is bounded (3 s):
  *                      a host that stops talking gets MMC_ERR_HIP from the run, not a hung GPU.
- *                      -1 (default) = use it for up to 128 replicas when it applies, 0 = never,
+ *                      -1 (default) = use it for up to 256 replicas (one per compute unit) when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
  *   "trace_steps"      test hook: see mmc_batch_get_trace
  *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 up to 16 replicas,
@@ -400,7 +400,7 @@ typedef struct {
                             chain depend on (seed, global index) only.  Its energies also depend,
                             in the last bits, on the order its dU terms are summed in, which the
                             batch picks from its own size (kernel by launch size, parts per move,
-                            move server up to 128 replicas): shardings that use the same
+                            move server up to 256 replicas): shardings that use the same
                             "kernel", n_parts and "persistent" / "server_wgs" on every rank
                             reproduce one another bit for bit; others agree to ~1e-13 per move
                             and may part ways at a Metropolis comparison eventually */
