@@ -150,6 +150,12 @@ static inline void mmc_bar_flush() { _mm_sfence(); } // push the write-combining
 #else
 static inline void mmc_bar_flush() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 #endif
+static inline void mmc_cpu_relax()
+{
+#if defined(__x86_64__)
+    _mm_pause();
+#endif
+}
 static inline void *mmc_bar_alloc(size_t bytes)
 {
     if (getenv("MMC_NO_BAR"))
