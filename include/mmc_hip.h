@@ -279,7 +279,7 @@ int32_t mmc_batch_volume_change(mmc_batch *b, double new_box, double new_kappa);
 /* One trial move per replica, one launch: moves[r] -> results[r].  moves[r].accept_prev settles
  * the replica's previous proposal first.  Synchronous. */
 int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *results);
-/* Workgroups per replica-move used by mmc_batch_eval (1..16; 1 = one workgroup does the whole
+/* Workgroups per replica-move used by mmc_batch_eval (1..32; 1 = one workgroup does the whole
  * move, >1 = the molecule range is split and the last workgroup does the reciprocal part). */
 int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
 /* Tuning switches (no effect on results beyond summation order):
@@ -288,11 +288,12 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      table; 1 = one workgroup per trial move (LDS-tiled, same table);
  *                      3 = 2 for launches of at least 16 moves per compute unit, else 1 (default
  *                      when every molecule has the same atom types and charges); 0 = generic;
- *                      4 = the latency form (k_move_eval_lat): "parts" (4, 8, 12 or 16) are waves,
+ *                      4 = the latency form (k_move_eval_lat): "parts" (4, 8, ... 128) are waves,
  *                      four to a workgroup, each pair part's molecules resident in the wave, three
  *                      lanes to a neighbour, the reciprocal sum split over 1..3 waves; the form the
  *                      move server takes for few replicas -- same chains bit for bit as that server
- *   "wave_wgs"         workgroups of a kernel-2 launch (0 = 4 per compute unit)
+ *   "wave_wgs"         workgroups of a kernel-2 launch (0 = 5 per compute unit: what its 96 VGPRs and
+ *                      31 KB of LDS let be resident)
  *   "inject_torn"      N > 0: the native driver corrupts its first N copies of result records
  *                      before checking them, as a torn PCIe write would (test hook: the check must
  *                      refuse them and read again; mmc_run_stats.torn_records counts them)
@@ -321,8 +322,8 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      -1 (default) = use it for up to 256 replicas (one per compute unit) when it applies, 0 = never,
  *                      1 = insist (MMC_ERR_UNSUPPORTED from the run when it cannot be used)
  *   "trace_steps"      test hook: see mmc_batch_get_trace
- *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 up to 16 replicas,
- *                      else 2 -- or, for a system too large for that, as many as it takes for
+ *   "server_wgs"       workgroups per replica of the move server: -1 (default) = 4 while each has
+ *                      a compute unit to itself (up to 64 replicas), else 2 -- or, for a system too large for that, as many as it takes for
  *                      every pair wave to hold at most 128 molecules (10 000 molecules: 21) --
  *                      while R x workgroups does not exceed the compute units; 0 = one workgroup
  *                      per replica (k_move_server_wave); 2..32 = that many (k_move_server_lat: each
