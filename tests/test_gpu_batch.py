@@ -159,7 +159,7 @@ def test_batch_parts_agree(orc):
     mv = g["moves"][0]
     ref = None
     for parts, kernel in ((1, 2), (2, 2), (1, 1), (2, 1), (3, 0), (5, 2), (9, 0), (16, 2),
-                          (16, 1), (1, 0)):
+                          (16, 1), (1, 0), (24, 2), (32, 1), (32, 0), (32, 2)):
         with make_batch(a, 2) as b:
             b.set_parts(parts)
             b.set_option("kernel", kernel)
