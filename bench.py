@@ -278,9 +278,11 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         **pmc_extras(name, moves_per_launch),
         "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
-        "what_binds": ("frac is ALGORITHMIC bytes (SURVEY 8d) over time; the kernel moves half of "
-                       "them (traffic) and is bound by fp64 VALU issue (valu_busy_frac) together with "
-                       "latency -- see DESIGN.md section 4") if name == "k_move_eval_wave" else
+        "what_binds": ("frac is ALGORITHMIC bytes (SURVEY 8d) over time and may exceed 1: the kernel "
+                       "moves well under half of them (traffic: old and new state share one scan and "
+                       "one gather, the scan reads 6-byte codes); it is bound by fp64 VALU issue "
+                       "(valu_busy_frac, valu_insts_per_move) together with latency -- see DESIGN.md "
+                       "section 4") if name == "k_move_eval_wave" else
                       ("latency: a launch of this size is a chain of dependent latencies, not a "
                        "stream of bytes -- see DESIGN.md section 4"),
         "avg_launch_us": 1e6 * t_launch, "launches": int(st["launches"]),
