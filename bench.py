@@ -535,12 +535,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
-    if args.threads <= 0:
-        # every rank spins its own worker threads: never oversubscribe the node's cores
-        cores = len(os.sched_getaffinity(0))
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        args.threads = max(1, min(8, (cores - local_world) // max(local_world, 1)))
-
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -551,6 +545,26 @@ def main():
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     red_device = "cuda" if backend == "nccl" else "cpu"
+    # Host threads: every rank spins its own workers (accept/reject, control words through the BAR),
+    # so before the first GPU call that creates a thread the rank pins itself to ITS slice of the
+    # cores on its GPU's NUMA node (no exec, no re-launch) and sizes its thread count to that slice
+    # -- never oversubscribing the node (sharding.plan_host_threads; MMC_NO_PIN=1 keeps the
+    # inherited affinity and the old rule min(8, (cores - ranks) / ranks)).
+    from metropolismontecarlo_amd import sharding as _sh
+    affinity0 = sorted(os.sched_getaffinity(0))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    pinned = None
+    if os.environ.get("MMC_NO_PIN"):
+        auto_threads = max(1, min(8, (len(affinity0) - local_world) // max(local_world, 1)))
+    else:
+        n_dev = torch.cuda.device_count()
+        addrs = []
+        for k in range(local_world):
+            p_ = torch.cuda.get_device_properties(k % n_dev)
+            addrs.append((p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id))
+        pinned, auto_threads = _sh.pin_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), addrs)
+    if args.threads <= 0:
+        args.threads = auto_threads
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -608,6 +622,8 @@ def main():
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
                        "groups_per_gpu": shape["groups"], "host_threads_per_gpu": shape["threads"],
+                       "host_cores_pinned": (f"{len(pinned)} cores of the GPU's NUMA node "
+                                             f"({pinned[0]}..{pinned[-1]})" if pinned else "inherited affinity"),
                        "prewarm_steps": shape["prewarm"],
                        "move_generation": "device" if args.device_moves else "host",
                        **({"short_run_note": f"the timed region of {shape['steps']} steps carries the fill "
@@ -696,6 +712,7 @@ def main():
             out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
             out["call_surface"] = call_surface(a)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
+            os.sched_setaffinity(0, affinity0)     # all cores of the host again
             mps, n, dt, tf = cpu_baseline(a, args.cpu_seconds)
             out["cpu_baseline"] = {
                 "value": mps, "unit": "moves/s", "cores": 1, "kind": "port",

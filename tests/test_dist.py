@@ -99,3 +99,127 @@ def test_shard_helpers():
     red, t = sharding.reduce_observables(dict(moves=3, accepted=1, overlaps=0, energy_sum=-1.5,
                                               kernel_ms=0.2, launches=3), 0.5)
     assert red["energy_sum"] == -1.5 and t == 0.5
+
+
+# ---- eight ranks: what the driver's 8-GPU node will run, rehearsed on CPU ------------------------
+def _worker8(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world), LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from metropolismontecarlo_amd import sharding
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r, lr, w = sharding.env_rank()
+    # BASELINE configs[2]: 256 replicas over the 8 GPUs of one node
+    mine = sharding.shard_total(256, r, w)
+    local = dict(moves=len(mine), accepted=sum(mine), overlaps=0, energy_sum=-1.0 * r,
+                 kernel_ms=0.0, launches=1)
+    red, tmax = sharding.reduce_observables(local, elapsed=float(r), dist=dist)
+    # the host-thread plan of this rank on a two-socket node: GPUs 0-3 on node 0, 4-7 on node 1
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]
+    cpus = {0: list(range(0, 48)) + list(range(96, 144)), 1: list(range(48, 96)) + list(range(144, 192))}
+    pin, nt = sharding.plan_host_threads(lr, nodes, cpus, range(192))
+    t = torch.zeros(world, 3, dtype=torch.int64)
+    t[r] = torch.tensor([min(pin), max(pin), nt])
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        q.put((red, tmax, t.tolist(), len(pin)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_shard_total_and_thread_plan():
+    sys.path.insert(0, ROOT)
+    world = 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    red, tmax, plan, n_pin = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert red["moves"] == 256 and red["accepted"] == sum(range(256)) and red["launches"] == 8
+    assert red["energy_sum"] == -28.0 and tmax == 7.0
+    # disjoint slices, each on its GPU's node, 8 threads each: 64 spinning threads on 192 cores
+    assert n_pin == 24
+    assert all(nt == 8 for _, _, nt in plan)
+    spans = sorted((lo, hi) for lo, hi, _ in plan)
+    assert all(a[1] < b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_thread_plan_rules():
+    sys.path.insert(0, ROOT)
+    from metropolismontecarlo_amd import sharding as sh
+    assert sh.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    # one rank, one GPU: the whole node next to the GPU, capped at 8 threads
+    pin, nt = sh.plan_host_threads(0, [1], {1: list(range(64, 128))}, range(128))
+    assert pin == list(range(64, 128)) and nt == 8
+    # restricted affinity (a container with 16 cores): what is allowed of that node
+    pin, nt = sh.plan_host_threads(0, [0], {0: list(range(0, 64))}, range(8, 24))
+    assert pin == list(range(8, 24)) and nt == 8
+    # unknown NUMA node: the ranks split the allowed cores evenly and never oversubscribe them
+    plans = [sh.plan_host_threads(r, [-1] * 8, {}, range(16)) for r in range(8)]
+    assert [len(p) for p, _ in plans] == [2] * 8 and all(nt == 1 for _, nt in plans)
+    assert sorted(c for p, _ in plans for c in p) == list(range(16))
+    # the node's cores are not in the allowed set at all -> fall back to the allowed ones
+    pin, nt = sh.plan_host_threads(0, [0], {0: [0, 1]}, [4, 5, 6])
+    assert pin == [4, 5, 6] and nt == 2
+    # a fake sysfs tree
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "bus/pci/devices/0000:c5:00.0"))
+        os.makedirs(os.path.join(d, "devices/system/node/node1"))
+        open(os.path.join(d, "bus/pci/devices/0000:c5:00.0/numa_node"), "w").write("1\n")
+        open(os.path.join(d, "devices/system/node/node1/cpulist"), "w").write("4-7\n")
+        assert sh.gpu_numa_node(0, 0xc5, 0, sysfs=d) == 1 and sh.node_cpus(1, sysfs=d) == [4, 5, 6, 7]
+        assert sh.gpu_numa_node(0, 0x01, 0, sysfs=d) == -1
+
+
+# ---- the RCCL unique-id hand-off of RcclReducer (a per-run file), two processes ------------------
+def _id_worker(rank, path, payload, delay, q):
+    sys.path.insert(0, ROOT)
+    import time
+    from metropolismontecarlo_amd import sharding
+    time.sleep(delay)
+    got = sharding.id_file_exchange(rank, payload if rank == 0 else None, path=path, timeout_s=30)
+    q.put((rank, got))
+
+
+def test_unique_id_exchange_ignores_a_stale_file_and_does_not_leak_into_the_next_run(tmp_path):
+    sys.path.insert(0, ROOT)
+    import time
+    from metropolismontecarlo_amd import sharding
+    path = str(tmp_path / "mmc_dist_id.test")
+    # a dead run's leftover, older than ID_MAX_AGE_S: a reader that starts BEFORE rank 0 must not take it
+    with open(path, "wb") as fh:
+        fh.write(b"\xee" * 128)
+    old = time.time() - 10 * sharding.ID_MAX_AGE_S
+    os.utime(path, (old, old))
+    ctx = mp.get_context("spawn")
+    for run, payload in enumerate((bytes(range(128)), bytes(range(128, 256)))):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_id_worker, args=(1, path, None, 0.0, q)),
+                 ctx.Process(target=_id_worker, args=(0, path, payload, 0.5, q))]
+        for p in procs:
+            p.start()
+        got = dict(q.get(timeout=60) for _ in procs)
+        for p in procs:
+            p.join(timeout=30)
+            assert p.exitcode == 0
+        assert got[0] == payload and got[1] == payload, run
+        sharding.id_file_done(path)          # what rank 0 does once mmc_dist_init has returned
+        assert not os.path.exists(path)
+    # distinct launches get distinct default names
+    os.environ["MASTER_PORT"] = "29500"
+    a = sharding.default_id_path()
+    os.environ["MASTER_PORT"] = "29501"
+    assert sharding.default_id_path() != a
+    os.environ.pop("MASTER_PORT")
+    with pytest.raises(ValueError):
+        sharding.id_file_exchange(1, b"x" * 128, path=path)

@@ -246,3 +246,29 @@ def test_context_server_of_a_large_system_equals_launch_per_evaluation():
     scale = np.abs(res[0][0]).max() + 1e4
     assert np.abs(res[1][0] - res[0][0]).max() < 1e-12 * scale
     assert np.abs(res[1][1] - res[0][1]).max() < 1e-11 * np.abs(res[0][1]).max()
+
+
+def test_nothing_else_runs_between_a_volume_trial_and_its_decision():
+    """Between mmc_volume_trial and accept / reject the context holds the trial volume: per-molecule
+    calls, updates and trial moves are refused (they would pull the host mirror to the trial volume,
+    which a rejection cannot undo); after the rejection everything answers as before the trial."""
+    from metropolismontecarlo_amd._lib import MMCError
+    a = common.nist_arrays(1, "unwrapped")
+    box = a["box"]
+    with common.device_context(a) as ctx:
+        ctx.potential_ewald(RCUT, RCUT)
+        before = ctx.lj_poly_du(3, RCUT) + ctx.ewald_short(3, RCUT)
+        L1 = box + 0.4
+        ctx.volume_trial(L1, 5.6 / L1, RCUT, RCUT)
+        for call in (lambda: ctx.lj_poly_du(3, RCUT), lambda: ctx.ewald_short(3, RCUT),
+                     lambda: ctx.set_molecule(3, a["com"][2], a["coords"][6:9]),
+                     lambda: ctx.update_system(a["com"], a["coords"]),
+                     lambda: ctx.trial_move(3, a["com"][2], a["coords"][6:9], RCUT, RCUT),
+                     lambda: ctx.recip_long(),
+                     lambda: ctx.volume_trial(L1, 5.6 / L1, RCUT, RCUT)):
+            with pytest.raises(MMCError, match="MMC_ERR_STATE"):
+                call()
+        ctx.volume_reject()
+        assert ctx.lj_poly_du(3, RCUT) + ctx.ewald_short(3, RCUT) == before
+        com, coords = ctx.download_system()
+        assert np.array_equal(com, a["com"]) and np.array_equal(coords, a["coords"])
