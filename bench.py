@@ -24,12 +24,14 @@ both as `named_configs`.
 One JSON line on stdout (rank 0).  Extra objects:
   roofline       dominant kernel (k_move_eval_wave for launches of >= 16 moves per CU, else
                  k_move_eval_fast): algorithmic bytes per launch (78.7 KB per
-                 trial move at 750 molecules x moves per launch) / average launch duration measured
-                 with HIP events on the kernel's own stream inside the timed region (every
-                 --event-every'th launch), against the 8 TB/s HBM peak.  `traffic` is NOT measured
-                 in this run (PMC counters cannot be read from inside the process): it is the
-                 rocprofv3 figure of the same command committed under profiles/, quoted only when
-                 the launch shape matches, and `traffic_source` says so.
+                 trial move at 750 molecules x moves per launch) / average launch duration, against
+                 the 8 TB/s HBM peak -- the contract's figure, NOT this kernel's ceiling -- and
+                 `binding`: the resource that does bind (fp64 vector issue; HBM on counter bytes),
+                 each with a frac <= 1 computed from this run's timing (see roofline_object for
+                 how a launch is timed when launches overlap).  `traffic`, instructions per move
+                 and the clock are NOT measured in this run (PMC counters cannot be read from
+                 inside the process): they are the rocprofv3 figures of the same command committed
+                 under profiles/, quoted only when the launch shape matches (`*_source`).
   full_energy_eval  M2: ns per potential(..., "ewald"), batched over the replicas and as the
                  latency of ONE system (750 and 10 000 molecules), each with its fraction of the
                  fp64 vector peak on the survey's flop count.
@@ -61,6 +63,7 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured
 FP64_PEAK_TFLOPS = 78.6   # fp64 vector peak (datasheet)
 N_K = 337
 N_CUS = 256
+N_SIMDS = 4 * N_CUS
 
 
 def algorithmic_bytes_per_move(n_mol, box, r_cut=RCUT, n_k=N_K):
@@ -115,7 +118,8 @@ def pmc_extras(kernel, moves_per_launch):
     if ex.get("kernel") != kernel or int(ex.get("moves_per_launch", -1)) != int(moves_per_launch):
         return {}
     out = {k: ex[k] for k in ("valu_insts_per_move", "valu_busy_frac", "clock_ghz", "hbm_traffic_gbs",
-                              "hbm_traffic_frac", "waves_per_simd") if k in ex}
+                              "hbm_traffic_frac", "waves_per_simd", "lds_busy_frac", "lds_conflict_frac",
+                              "wait_frac", "salu_insts_per_move") if k in ex}
     out["counters_source"] = f"profiles/{path} (rocprofv3 --pmc passes of this command; not measured in this run)"
     return out
 
@@ -236,9 +240,10 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, pers
     tot2 = b.potential_ewald(as_array=True)
     drift = float(np.max(np.abs(energies - tot2["energy"]) / np.abs(energies)))
     b.close()
+    streams = args.streams if args.streams > 0 else (min(shape["groups"], 2) if args.device_moves else shape["groups"])
     return dict(st=st, elapsed=elapsed, t_full=t_full, drift=drift, energy_sum=float(energies.sum()),
                 launches_per_step=st["launches"] / max(shape["steps"], 1),
-                server=st["server_steps"] > 0)
+                server=st["server_steps"] > 0, streams=streams)
 
 
 def launch_mode_roofline(R, a, args, local_rank, g0, barrier, shape, n_mol, box, parts_used):
@@ -265,32 +270,74 @@ def launch_mode_roofline(R, a, args, local_rank, g0, barrier, shape, n_mol, box,
 
 
 def roofline_object(res, R, args, shape, n_mol, box, parts_used):
+    """The contract's roofline object for the dominant kernel, from THIS run's timing.
+
+    Launch duration.  One stream: the HIP-event duration of a launch (events on the kernel's own
+    stream, every --event-every'th launch of the timed region) -- what rocprofv3's kernel trace
+    shows.  Two streams (the default with device-side proposals): launches of the two replica
+    groups overlap, an event pair then measures a launch's SPAN while it shares the GPU
+    (`launch_span_us`, also what rocprofv3 shows), not what it costs; the cost of a launch is the
+    timed region's wall time -- during which the GPU always has a move kernel running -- divided
+    by its launches (`avg_launch_us`; fill and drain of the pipeline included, so it errs high).
+
+    `achieved` / `frac` are the contract's ALGORITHMIC bytes over that duration and are
+    not a ceiling for this kernel (it moves 0.42 of them); what binds is in `binding`: fp64 vector
+    issue -- vector instructions per move x moves per launch / duration against 1024 SIMDs x clock
+    / 4 cycles per wave64 instruction -- and HBM throughput on counter bytes.  Instructions per
+    move, bytes per move and the clock under this load come from the committed rocprofv3 PMC
+    passes of this command (profiles/, `counters_source`), the durations from this run."""
     st = res["st"]
-    if args.no_events or not st["timed_launches"]:
+    if not st["launches"]:
         return None
     bytes_move = algorithmic_bytes_per_move(n_mol, box)
     moves_per_launch = st["moves"] / max(st["launches"], 1)
-    t_launch = st["kernel_ms"] * 1e-3 / st["timed_launches"]
+    overlapped = res.get("streams", 1) > 1 and shape["groups"] > 1
+    span = (st["kernel_ms"] * 1e-3 / st["timed_launches"]) if st["timed_launches"] else None
+    if overlapped or span is None:
+        t_launch = res["elapsed"] / st["launches"]
+        t_source = ("timed region wall time / launches: launches of the replica groups overlap on two "
+                    "streams, the GPU runs a move kernel throughout")
+    else:
+        t_launch = span
+        t_source = "HIP events around single launches (every Nth) on the kernel's stream"
     achieved = bytes_move * moves_per_launch / t_launch / 1e9
     name = kernel_name(args.kernel, moves_per_launch, parts_used)
     traffic, source = pmc_traffic(name, moves_per_launch)
-    return {
-        **pmc_extras(name, moves_per_launch),
+    ex = pmc_extras(name, moves_per_launch)
+    out = {
         "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
-        "what_binds": ("frac is ALGORITHMIC bytes (SURVEY 8d) over time and may exceed 1: the kernel "
-                       "moves well under half of them (traffic: old and new state share one scan and "
-                       "one gather, the scan reads 6-byte codes); it is bound by fp64 VALU issue "
-                       "(valu_busy_frac, valu_insts_per_move) together with latency -- see DESIGN.md "
-                       "section 4") if name == "k_move_eval_wave" else
-                      ("latency: a launch of this size is a chain of dependent latencies, not a "
-                       "stream of bytes -- see DESIGN.md section 4"),
-        "avg_launch_us": 1e6 * t_launch, "launches": int(st["launches"]),
+        "frac_note": ("frac is the contract's ALGORITHMIC bytes (SURVEY 8d: COM scan and neighbour gather "
+                      "counted once per state, 24 B per centre of mass) over time; the kernel moves 0.42 of "
+                      "them (one scan and one gather for both states, 6-byte codes), so this frac may exceed "
+                      "1 and is not the ceiling: see `binding`") if name == "k_move_eval_wave" else
+                     ("latency: a launch of this size is a chain of dependent latencies, not a stream of "
+                      "bytes -- see DESIGN.md section 4"),
+        "avg_launch_us": 1e6 * t_launch, "avg_launch_us_is": t_source,
+        "launch_span_us": 1e6 * span if span is not None else None,
+        "launches": int(st["launches"]),
         "launches_timed_with_events": int(st["timed_launches"]),
         "algorithmic_bytes_per_move": bytes_move, "moves_per_launch": moves_per_launch,
         "launches_per_move": st["launches"] / max(st["moves"], 1),
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
+    if ex.get("valu_insts_per_move") and ex.get("clock_ghz"):
+        insts = ex["valu_insts_per_move"] * moves_per_launch / t_launch / 1e9   # G wave-instructions / s
+        peak = N_SIMDS * ex["clock_ghz"] / 4.0
+        b = {"bound": "fp64_valu_issue", "achieved": insts, "peak": peak, "unit": "G wave64 instructions/s",
+             "frac": insts / peak, "valu_insts_per_move": ex["valu_insts_per_move"], "clock_ghz": ex["clock_ghz"],
+             "peak_is": f"{N_SIMDS} SIMDs x clock / 4 cycles per wave64 vector instruction (fp64 and fp32 alike)",
+             "counters_source": ex["counters_source"]}
+        if traffic:
+            hb = traffic / t_launch / 1e9
+            b["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
+                        "bytes_per_move": traffic / moves_per_launch,
+                        "frac_of_measured_copy_peak_6290": hb / 6290.0}
+        for k in ("lds_busy_frac", "lds_conflict_frac", "wait_frac", "salu_insts_per_move", "waves_per_simd"):
+            if k in ex:
+                b[k] = ex[k]
+        out["binding"] = b
+    return out
 
 
 def single_system_latency(a, local_rank):
@@ -621,14 +668,15 @@ def main():
             "config": {"workload": "SPC/E 750 molecules NVT 298.15 K, full Ewald (337 k), "
                                    "r_cut 10 A, independent replicas",
                        "replicas_per_gpu": R, "replicas_total": R * world,
-                       "groups_per_gpu": shape["groups"], "host_threads_per_gpu": shape["threads"],
+                       "groups_per_gpu": shape["groups"], "streams_per_gpu": res["streams"],
+                       "host_threads_per_gpu": shape["threads"],
                        "host_cores_pinned": (f"{len(pinned)} cores of the GPU's NUMA node "
                                              f"({pinned[0]}..{pinned[-1]})" if pinned else "inherited affinity"),
                        "prewarm_steps": shape["prewarm"],
                        "move_generation": "device" if args.device_moves else "host",
                        **({"short_run_note": f"the timed region of {shape['steps']} steps carries the fill "
                            "and drain of the two-group pipeline (about one kernel time in "
-                           f"{2 * shape['steps']}): a 600-step run of the same command reads ~6 % higher"}
+                           f"{2 * shape['steps']}): a 600-step run of the same command reads ~7 % higher"}
                           if shape["steps"] < 100 else {}),
                        "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),
@@ -693,22 +741,28 @@ def main():
                 if rf2:
                     entry["roofline"] = rf2
                 out["named_configs"][name] = entry
-            if R >= 4096 and args.streams == 0 and not res["server"]:
-                # The same workload with the two groups on TWO streams: their launches overlap (the
-                # start of one fills the tail of the other; no gap between launches), so a launch's
-                # own span no longer says what it costs -- which is why the headline line keeps one
-                # stream, where event time, trace time and step time add up.
-                a2 = argparse.Namespace(**{**vars(args), "streams": 2})
-                sh2 = dict(shape, steps=min(shape["steps"], 200), warmup=min(shape["warmup"], 20), prewarm=0)
-                r_ = measure_moves(R, a, a2, local_rank, g0, barrier, sh2)
-                out["two_streams"] = {
+            if R >= 4096 and args.streams == 0 and not res["server"] and res["streams"] > 1:
+                # The same workload with every launch ALONE on the GPU (one stream): event time,
+                # rocprofv3 trace time and step time then add up, and the kernel's own duration can
+                # be read -- but the start of every launch (5120 waves in step) and its end (a
+                # thinning tail) are paid in full: the headline's two streams overlap them.
+                # Same pre-warm as the headline (a cold side run was what made round 3's
+                # `two_streams` line read 6.7e7 in the driver's run).
+                a1 = argparse.Namespace(**{**vars(args), "streams": 1})
+                sh1 = dict(shape, steps=min(max(shape["steps"], 100), 200), warmup=min(shape["warmup"], 20),
+                           prewarm=100)
+                r_ = measure_moves(R, a, a1, local_rank, g0, barrier, sh1)
+                rf1 = roofline_object(r_, R, a1, sh1, n_mol, box, parts_used)
+                out["one_stream"] = {
                     "value": r_["st"]["moves"] / r_["elapsed"], "unit": "moves/s",
-                    "ms_per_step": 1e3 * r_["elapsed"] / sh2["steps"], "steps": sh2["steps"],
-                    "launch_span_us": (1e3 * r_["st"]["kernel_ms"] / r_["st"]["timed_launches"]
-                                       if r_["st"]["timed_launches"] else None),
+                    "ms_per_step": 1e3 * r_["elapsed"] / sh1["steps"], "steps": sh1["steps"],
+                    "avg_launch_us": rf1["avg_launch_us"] if rf1 else None,
+                    "avg_launch_us_is": rf1["avg_launch_us_is"] if rf1 else None,
+                    "frac": rf1["frac"] if rf1 else None,
+                    "binding_frac": rf1.get("binding", {}).get("frac") if rf1 else None,
                     "energy_drift_rel": r_["drift"],
-                    "note": "launches of the two groups overlap: launch_span_us is the span of one "
-                            "launch sharing the GPU with the other, not its cost (ms_per_step / 2 is)"}
+                    "note": "every launch alone on the GPU: its HIP-event duration is its cost and is what "
+                            "rocprofv3 --kernel-trace reports for `--streams 1` (profiles/)"}
             out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
             out["call_surface"] = call_surface(a)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only

@@ -394,7 +394,9 @@ typedef struct {
                             stats.timed_launches); 0: none */
     int32_t n_threads;   /* host threads sharing the groups (0 or 1 = the calling thread only) */
     int32_t n_streams;   /* HIP streams the groups are spread over; 0 = choose (one per group with
-                            host proposals, one for all with "device_moves") */
+                            host proposals; two with "device_moves": the launches of the groups
+                            overlap -- stats.kernel_ms then sums SPANS of launches that share the
+                            GPU, not costs; 1 = every launch alone on the GPU) */
     int32_t _pad;
     uint64_t replica0;   /* global index of this batch's replica 0 (a rank that owns chains
                             [g0, g0 + R) of a larger ensemble passes g0): the RANDOM DRAWS of a
@@ -420,7 +422,8 @@ typedef struct {
     int64_t moves, launches;
     int64_t trans_attempt, trans_accept, rot_attempt, rot_accept, overlaps;
     double wall_ms;      /* host wall clock over the run */
-    double kernel_ms;    /* sum of HIP-event durations of the move kernel (time_kernels) */
+    double kernel_ms;    /* sum of HIP-event durations of the move kernel (time_kernels); with more
+                            than one stream launches overlap and a duration is the launch's span */
     double energy_sum;   /* sum over replicas of the running total energy at the end */
     int64_t timed_launches; /* launches that contributed to kernel_ms */
     int64_t torn_records;   /* result records that carried the launch stamp but failed their

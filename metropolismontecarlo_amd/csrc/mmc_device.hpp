@@ -16,6 +16,7 @@
 #define MMC_LIST_CAP 2048 // neighbour-list slots per chunk (8 KiB of LDS)
 #define MMC_MAX_ATOMS 16  // atoms in the CHOSEN molecule (neighbours are unbounded)
 #define MMC_NKTAB 11      // phase-table width for nk = 5: k = -5..5
+#define MMC_NK_STRIDE 352 // >= 337 k-vectors, 16-element aligned: entries per k-indexed device array
 
 // One replica's state as the kernels see it.  Structure-of-arrays so that lane j reading
 // molecule j (or atom j) is a unit-stride, fully coalesced HBM/L2 access.

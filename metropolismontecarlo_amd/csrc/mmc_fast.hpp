@@ -289,12 +289,32 @@ __global__ void k_broadcast_f32(float *p, int64_t per_replica)
         p[r * per_replica + i] = p[i];
 }
 
-// k-vector constants packed for one load per k: kx | (ky+5) << 4 | (kz+5) << 8
-__global__ void k_pack_kvec(const int32_t *kxyz, int n, int32_t *kpack)
+// k-vector constants packed for one load per k: kx | (ky+5) << 4 | (kz+5) << 8 | column << 12, where
+// `column` numbers the distinct (kx, ky) pairs in the order the k-vectors list them (50 of them for
+// nk = 5, k^2 < 27; 63 stands for "past the 63rd").  The (kx, ky) of column c, packed the same way,
+// is kpack[MMC_NK_STRIDE + c] (MMC_KCOLS entries, 0 past the last column): k_move_eval_wave builds
+// the products e^{i kx x} e^{i ky y} of the moved atoms once per column, not once per k-vector.
+// One block of MMC_NK_STRIDE threads.
+#define MMC_KCOLS 64
+__global__ void k_pack_kvec(const int32_t *kxyz, const int32_t *n_kvecs, int32_t *kpack)
 {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n)
-        kpack[k] = kxyz[3 * k] | ((kxyz[3 * k + 1] + 5) << 4) | ((kxyz[3 * k + 2] + 5) << 8);
+    const int k = threadIdx.x, n = min(*n_kvecs, MMC_NK_STRIDE);
+    if (k < MMC_KCOLS)
+        kpack[MMC_NK_STRIDE + k] = 0;
+    __syncthreads();
+    if (k >= n) {
+        if (k < MMC_NK_STRIDE)
+            kpack[k] = 0;
+        return;
+    }
+    auto key = [&](int j) { return kxyz[3 * j] * 16 + (kxyz[3 * j + 1] + 5); };
+    int col = 0;
+    for (int j = 1; j <= k; j++)
+        col += key(j) != key(j - 1);
+    const int xy = kxyz[3 * k] | ((kxyz[3 * k + 1] + 5) << 4);
+    kpack[k] = xy | ((kxyz[3 * k + 2] + 5) << 8) | ((col < MMC_KCOLS - 1 ? col : MMC_KCOLS - 1) << 12);
+    if (col < MMC_KCOLS && (k == 0 || key(k) != key(k - 1)))
+        kpack[MMC_NK_STRIDE + col] = xy;
 }
 
 struct FastShared {
@@ -689,10 +709,11 @@ __global__ __launch_bounds__(MMC_BLOCK) void k_move_eval_fast(
 
 // settle for the record layout: as k_settle, plus rec.
 __global__ void k_settle_rec(BatchView bv, double *rec, const MoveRec *prev,
-                             const int32_t *accept, int r_base)
+                             const int32_t *accept, int r_base, int nr)
 {
-    const int r = r_base + blockIdx.x, t = threadIdx.x;
-    if (!accept[r] || t >= 12)
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), t = threadIdx.x & 15;
+    const int r = r_base + q;
+    if (q >= nr || !accept[r] || t >= 12)
         return;
     const int m = prev[r].mol - 1;
     const double v = (t < 9) ? prev[r].atoms_new[t] : prev[r].com_new[t - 9];

@@ -37,7 +37,6 @@ void mmc_set_error(const char *fmt, ...);
 
 #define MMC_MAX_PARTS 32 // result records (units) per trial move
 static_assert(LAT_MAX_PARTS / LAT_WAVES <= MMC_MAX_PARTS, "one record per workgroup of the latency kernels");
-#define MMC_NK_STRIDE 352 // >= 337 k-vectors, 16-element aligned
 
 // Device state of R replicas of one system + Ewald tables.  R = 1 for a context.
 struct DeviceSystem {
@@ -56,10 +55,11 @@ struct DeviceSystem {
     double r_mol_max = 0.0;
     void note_shape(const double *com, const double *coords); // one replica's host arrays
     bool image_by_molecule(double gate_sq) const;
+    bool pairs_inside_slack(double gate_sq, double slack_sq) const;
     double *rec = nullptr;    // [R][n_mol][MMC_RSTRIDE], only when homogeneous
     FastConsts fc{};          // launch constants of the fast kernels
     double *qq_tab = nullptr; // [MMC_QQ_NINT][MMC_QQ_NCOEF] for the prepared kappa
-    int32_t *kpack = nullptr; // [MMC_NK_STRIDE] packed k-vectors (k_pack_kvec)
+    int32_t *kpack = nullptr; // [MMC_NK_STRIDE + MMC_KCOLS] packed k-vectors and their (kx, ky) columns (k_pack_kvec)
     int16_t *tile_pairs = nullptr; // [n_tile_pairs][2], I <= J (k_total_pairs)
     int n_tile_pairs = 0;
     TotalPart *d_tparts = nullptr; // [R][n_tile_pairs], lazily

@@ -594,10 +594,13 @@ __global__ void k_set_molecule(BatchView bv, SetMolArgs a, double *rec)
 
 // Commit the outstanding proposal of every replica whose accept flag is set (main.jl:598-621),
 // without evaluating a new one.  grid R, block 64.
-__global__ void k_settle(BatchView bv, const MoveRec *prev, const int32_t *accept, int r_base)
+// (16 lanes per replica, 16 replicas per block of 256: a block per replica was 32768 blocks of
+// which 48 lanes each did nothing -- 100 us of a run's fixed cost)
+__global__ void k_settle(BatchView bv, const MoveRec *prev, const int32_t *accept, int r_base, int nr)
 {
-    const int r = r_base + blockIdx.x, t = threadIdx.x;
-    if (!accept[r] || t >= 16)
+    const int q = blockIdx.x * 16 + (threadIdx.x >> 4), t = threadIdx.x & 15;
+    const int r = r_base + q;
+    if (q >= nr || !accept[r])
         return;
     const int m = prev[r].mol - 1;
     if (t >= 12) {

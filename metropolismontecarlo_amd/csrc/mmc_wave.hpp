@@ -245,6 +245,10 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
 #define WV_IMG IMG
+#ifndef WV_XY_MOVE
+#define WV_XY_MOVE 1
+#endif
+#define WV_XY WV_XY_MOVE
 #define WV_PASSES 2 // (105-111 VGPRs unconstrained instead of 137-151: what makes WV_OCC = 5 possible)
     // (n_parts == 1: every unit has the reciprocal part, and the commit's stores, issued before the
     // phase tables were computed, have mostly landed when those are done)
@@ -255,6 +259,7 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #undef WV_AFTER_PHASE_TABLES
 #undef WV_IMG
 #undef WV_PASSES
+#undef WV_XY
 #undef WV_SUBST
 #undef WV_ZERO
 #undef WV_CQ_BASE
@@ -390,7 +395,9 @@ __device__ __forceinline__ void total_wave_body(
                     // scalar mask arithmetic and the table's row of zeros, as in mmc_wave_unit.inc
                     // (ewalds.jl:359, :362)
                     const unsigned long long cm0 = wave_ballot(u0 < pp.ovr) & gm0;
-                    const unsigned long long im0 = wave_ballot(u0 < pp.qq_slack_sq) & (qneg ? gm0 & ~cm0 : gm0);
+                    // (IMG also promises (gate + 2 r_mol)^2 < r_cut^2 + 100: no atom pair of a gated
+                    // molecule pair can fail the slack tests, as in mmc_wave_unit.inc)
+                    const unsigned long long im0 = (IMG ? ~0ULL : wave_ballot(u0 < pp.qq_slack_sq)) & (qneg ? gm0 & ~cm0 : gm0);
                     double e0 = qq_table_eval_lanes(sm.qtab, u0, im0);
                     if (qneg) {
                         ovm |= cm0;
@@ -400,7 +407,7 @@ __device__ __forceinline__ void total_wave_body(
                     a_q = fma(e0, qq, a_q);
                     const double eps = fc.eps9[ab], sg = fc.sig9[ab];
                     if ((fc.lj_mask >> ab) & 1) { // uniform (energy.jl:270: eps > 0.001)
-                        if (l0 && u0 < pp.lj_slack_sq) {
+                        if (l0 && (IMG || u0 < pp.lj_slack_sq)) {
                             const double s2 = sg * sg / u0;
                             const double s6 = s2 * s2 * s2;
                             const double s12 = s6 * s6;

@@ -42,7 +42,13 @@ for r in csv.DictReader(open(newest("trace/*/*kernel_trace.csv"))):
 main_grid = max(dur, key=lambda g: sum(dur[g]))
 trace = {"kernel": KERNEL, "grid_threads": main_grid, "calls": len(dur[main_grid]),
          "avg_us": sum(dur[main_grid]) / len(dur[main_grid]) / 1e3,
-         "bench_events_avg_us": bench["roofline"]["avg_launch_us"]}
+         "bench_events_avg_us": (bench.get("one_stream") or {}).get("avg_launch_us") or bench["roofline"]["avg_launch_us"],
+         "note": "trace and PMC passes run `bench.py --streams 1` (every launch alone on the GPU: its duration is "
+                 "its cost); the default's two streams overlap launches -- their spans are in *_two_stream_kernel_stats.csv"}
+try:
+    shutil.copy(newest("trace2/*/*kernel_stats.csv"), os.path.join(DST, f"{TAG}_two_stream_kernel_stats.csv"))
+except SystemExit:
+    pass
 
 pmc = {}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq1", "pmc_sq2"):
@@ -81,6 +87,16 @@ if wc and "SQ_ACTIVE_INST_VALU" in pmc and w:
     # (SQ_WAVE_CYCLES counts quad-cycles summed over the resident waves: x 4 / waves / duration is
     # the shader clock the counters imply while the kernel runs)
     extras["clock_ghz"] = wc * 4.0 / (n_simd * waves_per_simd) / (trace["avg_us"] * 1e3)
+if "SQ_INSTS_SALU" in pmc:
+    extras["salu_insts_per_move"] = pmc["SQ_INSTS_SALU"]["per_dispatch"] / moves_per_launch
+if wc and "SQ_WAIT_ANY" in pmc:
+    extras["wait_frac"] = pmc["SQ_WAIT_ANY"]["per_dispatch"] / wc
+if "SQ_LDS_IDX_ACTIVE" in pmc and "clock_ghz" in extras:
+    # LDS-array cycles summed over the 256 compute units against the cycles of the launch
+    cu_cycles = 256 * extras["clock_ghz"] * 1e3 * trace["avg_us"]
+    extras["lds_busy_frac"] = pmc["SQ_LDS_IDX_ACTIVE"]["per_dispatch"] / cu_cycles
+    if "SQ_LDS_BANK_CONFLICT" in pmc:
+        extras["lds_conflict_frac"] = pmc["SQ_LDS_BANK_CONFLICT"]["per_dispatch"] / pmc["SQ_LDS_IDX_ACTIVE"]["per_dispatch"]
 if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
     hbm = (2 * pmc["FETCH_SIZE"]["per_dispatch"] + pmc["WRITE_SIZE"]["per_dispatch"]) * 1024
     extras["hbm_traffic_gbs"] = hbm / (trace["avg_us"] * 1e-6) / 1e9
