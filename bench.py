@@ -396,24 +396,35 @@ def single_system_latency(a, local_rank):
                                             "energy_after_rejections_K": e_back,
                                             "host_round_trips": 0}
         ctx.close()
-        if nm == 10000:   # ... and the trial moves between two volume moves: one chain of this system
+        if nm == 10000:   # configs[3] as a CHAIN: sweeps of trial moves and volume moves on ONE device state
             from metropolismontecarlo_amd.device import Batch
             b = Batch(1, s["com"], s["coords"], s["atype"], s["charge"], s["eps"], s["sig"], s["box"],
                       5.6 / s["box"], structs.factor, RCUT, RCUT, device=local_rank)
             b.set_option("device_moves", 1)
-            e0 = b.potential_ewald(as_array=True)["energy"].copy()
-            e0, _ = b.run(300, TEMPERATURE, DR_MAX, DPHI_MAX, SEED, e0, n_groups=1, n_threads=1)
-            n_mv = 3000
+            e0 = float(b.potential_ewald(as_array=True)["energy"][0])
+            vmax = 0.002 * s["box"] ** 3          # dV uniform in +-0.1 % of V
+            e0, _, _ = b.run_npt(1, TEMPERATURE, 0.0, vmax, DR_MAX, DPHI_MAX, SEED, e0, moves_per_sweep=300)
+            n_sw = 3
             t0 = time.perf_counter()
-            e1, st = b.run(n_mv, TEMPERATURE, DR_MAX, DPHI_MAX, SEED + 1, e0, n_groups=1, n_threads=1)
+            e1, st, ns = b.run_npt(n_sw, TEMPERATURE, 0.0, vmax, DR_MAX, DPHI_MAX, SEED + 1, e0)
             dt = time.perf_counter() - t0
-            e2 = b.potential_ewald(as_array=True)["energy"]
-            out["npt_trial_moves_10000"] = {
-                "us_per_move": 1e6 * dt / n_mv, "moves": n_mv,
+            e2 = float(b.potential_ewald(as_array=True)["energy"][0])
+            out["npt_sweep_10000"] = {
+                "workload": "BASELINE configs[3]: ONE chain of 10 000 SPC/E molecules, NPT: sweeps of 10 000 trial "
+                            "moves (Loop(), main.jl:487-644) each followed by one volume move "
+                            "(volumeChange.jl:59-147: rescale, k-vectors and tables rebuilt, total energy), "
+                            "all on one device state (mmc_batch_run_npt)",
+                "sweeps": n_sw, "trial_moves": int(st["moves"]), "volume_moves": int(ns["vol_attempt"]),
+                "moves_per_s_including_volume_moves": (st["moves"] + ns["vol_attempt"]) / dt,
+                "us_per_trial_move": 1e3 * st["wall_ms"] / max(st["moves"], 1),
+                "ms_per_volume_move": ns["volume_ms"] / max(ns["vol_attempt"], 1),
+                "ms_per_sweep": 1e3 * dt / n_sw,
                 "driver": "persistent move server" if st["server_steps"] else "one launch per step",
                 "workgroups_per_replica": server_lat_parts(1, nm) // 4,
                 "acceptance": (st["trans_accept"] + st["rot_accept"]) / max(st["moves"], 1),
-                "energy_drift_rel": float(np.abs(e1 - e2).max() / np.abs(e2).max())}
+                "volume_acceptance": ns["vol_accept"] / max(ns["vol_attempt"], 1),
+                "box_A": ns["box"],
+                "energy_drift_rel": abs(e1 - e2) / abs(e2)}
             b.close()
     return out
 

@@ -276,6 +276,18 @@ int32_t mmc_batch_recip_long(mmc_batch *b, double *energies);
 int32_t mmc_batch_potential_ewald(mmc_batch *b, mmc_totals *tot);
 /* mmc_volume_change for every replica of the batch (they share one box). */
 int32_t mmc_batch_volume_change(mmc_batch *b, double new_box, double new_kappa);
+/* An NPT volume move of a ONE-replica batch without a host round trip -- the batch-side twin of
+ * mmc_volume_trial / accept / reject, so that the trial moves of an NPT chain run on the batch's
+ * fast paths (the move server: BASELINE configs[3], 10 000 molecules) and its volume moves on
+ * the same state (the reference's only statement of the move: the docstring
+ * Ewald/volumeChange.jl:59-147).  Trial: everything the move rewrites is copied aside on the device,
+ * the system rescaled about the centres of mass (:62-80), the tables rebuilt for new_kappa
+ * (ewalds.jl:45-103) and the total energy at the new volume evaluated (:91-111).  Accept (:132-147):
+ * nothing to do.  Reject: the copy back, bit for bit.  A batch has ONE box: independent NPT
+ * replicas are one batch each (MMC_ERR_UNSUPPORTED for more than one replica). */
+int32_t mmc_batch_volume_trial(mmc_batch *b, double new_box, double new_kappa, mmc_totals *tot);
+int32_t mmc_batch_volume_accept(mmc_batch *b);
+int32_t mmc_batch_volume_reject(mmc_batch *b);
 /* One trial move per replica, one launch: moves[r] -> results[r].  moves[r].accept_prev settles
  * the replica's previous proposal first.  Synchronous. */
 int32_t mmc_batch_eval(mmc_batch *b, const mmc_move *moves, mmc_move_result *results);
@@ -431,6 +443,33 @@ typedef struct {
     int64_t server_steps;   /* steps that ran on the persistent move server (option "persistent"):
                                `launches` then counts control-word posts, not kernel launches */
 } mmc_run_stats;
+
+/* An NPT chain of a one-replica batch: n_sweeps times { moves_per_sweep trial moves (mmc_batch_run:
+ * Loop(), Ewald/main.jl:487-644), then ONE volume move } -- Ewald/volumeChange.jl:59-147:
+ *   vol_new = vol_old + (rand() - 0.5) * vmax                         :59
+ *   test = exp(-beta (P dV - N ln(vol_new / vol_old) / beta + dE))    :129-130
+ *   accepted if rand() < test                                         :132
+ * with beta = 1 / temperature (energies are in K, so the pressure is in K / A^3), kappa = alpha /
+ * L_new (Ewald/main.jl:290-291) and dE from the full recompute at the new volume.  The host decides;
+ * the two uniforms of a volume move are Philox draws of the chain's own stream (seed, replica0)
+ * at the step count it has reached, slot MMC_SLOT_VOLUME.  A move to a box below 2 r_cut is
+ * rejected outright.  energy: in/out, the running total of the replica. */
+#define MMC_SLOT_VOLUME 0x40000000u /* Philox slot of a volume move's two uniforms */
+typedef struct {
+    double pressure;         /* K / A^3 */
+    double vmax;             /* A^3: dV is uniform in +- vmax / 2 */
+    double alpha;            /* kappa * L (5.6 in Ewald/main.jl:290) */
+    int64_t n_sweeps;
+    int64_t moves_per_sweep; /* 0 = one per molecule (Ewald/main.jl:490) */
+} mmc_npt_params;
+typedef struct {
+    int64_t vol_attempt, vol_accept;
+    double box;              /* at the end */
+    double volume_sum;       /* sum over the sweeps of the volume after each volume move */
+    double volume_ms;        /* host wall clock spent in the volume moves */
+} mmc_npt_stats;
+int32_t mmc_batch_run_npt(mmc_batch *b, const mmc_run_params *p, const mmc_npt_params *q,
+                          double *energy, mmc_run_stats *stats, mmc_npt_stats *npt_stats);
 
 /* The driver's counter-based generator, exposed for known-answer tests and for callers that
  * want to re-derive a chain's draws: Philox4x32-10 (Salmon, Moraes, Dror, Shaw, SC'11). */

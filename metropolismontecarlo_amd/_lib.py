@@ -67,6 +67,21 @@ class RunStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class NptParams(C.Structure):
+    """mmc_npt_params"""
+    _fields_ = [("pressure", C.c_double), ("vmax", C.c_double), ("alpha", C.c_double),
+                ("n_sweeps", C.c_int64), ("moves_per_sweep", C.c_int64)]
+
+
+class NptStats(C.Structure):
+    """mmc_npt_stats"""
+    _fields_ = [("vol_attempt", C.c_int64), ("vol_accept", C.c_int64), ("box", C.c_double),
+                ("volume_sum", C.c_double), ("volume_ms", C.c_double)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 # mmc_totals as a numpy record (Batch.potential_ewald(as_array=True): no per-replica Python objects)
 TOTALS_DTYPE = np.dtype([("energy", "f8"), ("virial", "f8"), ("coulomb", "f8"), ("lj", "f8"),
                          ("real", "f8"), ("recip", "f8"), ("self", "f8"), ("n_overlap", "i4"),
@@ -100,6 +115,11 @@ SIGNATURES = {
     "mmc_download_system": [_vp, _dp, _dp],
     "mmc_volume_change": [_vp, _d, _d],
     "mmc_batch_volume_change": [_vp, _d, _d],
+    "mmc_batch_volume_trial": [_vp, _d, _d, C.POINTER(Totals)],
+    "mmc_batch_volume_accept": [_vp],
+    "mmc_batch_volume_reject": [_vp],
+    "mmc_batch_run_npt": [_vp, C.POINTER(RunParams), C.POINTER(NptParams), _dp, C.POINTER(RunStats),
+                          C.POINTER(NptStats)],
     "mmc_volume_trial": [_vp, _d, _d, _d, _d, C.POINTER(Totals)],
     "mmc_volume_accept": [_vp],
     "mmc_volume_reject": [_vp],

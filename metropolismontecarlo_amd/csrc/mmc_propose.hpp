@@ -38,6 +38,8 @@ __host__ __device__ inline Philox philox4x32_10(uint32_t c0, uint32_t c1, uint32
 
 // Slots of one (chain, step): each slot yields two uniforms in [0, 1).
 enum { MMC_SLOT_KIND = 0, MMC_SLOT_MOVE = 1, MMC_SLOT_METROPOLIS = 2, MMC_SLOT_AXIS = 3 };
+// (the axis slots count up from 3; the volume move of an NPT chain draws from MMC_SLOT_VOLUME =
+// 0x40000000, include/mmc_hip.h)
 
 struct Uniform2 {
     double a, b;

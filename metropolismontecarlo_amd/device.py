@@ -377,6 +377,32 @@ class Batch:
     def volume_change(self, new_box, new_kappa):
         check(self._L.mmc_batch_volume_change(self._h, float(new_box), float(new_kappa)))
 
+    def volume_trial(self, new_box, new_kappa):
+        """mmc_batch_volume_trial (a batch of ONE replica): device-side snapshot, rescale, new
+        tables, total energy at the new volume.  Follow with volume_accept() or volume_reject()."""
+        t = Totals()
+        check(self._L.mmc_batch_volume_trial(self._h, float(new_box), float(new_kappa), C.byref(t)))
+        return t.asdict()
+
+    def volume_accept(self):
+        check(self._L.mmc_batch_volume_accept(self._h))
+
+    def volume_reject(self):
+        check(self._L.mmc_batch_volume_reject(self._h))
+
+    def run_npt(self, n_sweeps, temperature, pressure, vmax, dr_max, dphi_max, seed, energy,
+                moves_per_sweep=0, alpha=5.6, n_parts=0, n_threads=1, replica0=0):
+        """mmc_batch_run_npt: n_sweeps x { moves_per_sweep trial moves (0 = one per molecule), one
+        volume move (Ewald/volumeChange.jl:59-147) }.  Returns (energy, run stats, npt stats)."""
+        from ._lib import NptParams, NptStats
+        p = RunParams(float(temperature), float(dr_max), float(dphi_max), int(seed), 0, 1,
+                      int(n_parts), 0, int(n_threads), 0, 0, int(replica0))
+        q = NptParams(float(pressure), float(vmax), float(alpha), int(n_sweeps), int(moves_per_sweep))
+        st, ns = RunStats(), NptStats()
+        e = np.array([float(energy)])
+        check(self._L.mmc_batch_run_npt(self._h, C.byref(p), C.byref(q), _d(e), C.byref(st), C.byref(ns)))
+        return float(e[0]), st.asdict(), ns.asdict()
+
     def qq_table(self, r2):
         r2 = _f64(r2).ravel()
         out = np.empty_like(r2)

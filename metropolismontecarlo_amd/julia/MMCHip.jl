@@ -122,6 +122,16 @@ struct MMCRunStats
     timed_launches::Int64; torn_records::Int64; server_steps::Int64
 end
 
+struct MMCNptParams
+    pressure::Float64; vmax::Float64; alpha::Float64
+    n_sweeps::Int64; moves_per_sweep::Int64
+end
+
+struct MMCNptStats
+    vol_attempt::Int64; vol_accept::Int64
+    box::Float64; volume_sum::Float64; volume_ms::Float64
+end
+
 struct MMCChain
     dr_max::Float64; dphi_max::Float64
     energy::Float64; virial::Float64
@@ -430,6 +440,38 @@ end
 volume_change!(b::Batch, new_box::Float64, new_kappa::Float64) =
     check(ccall((:mmc_batch_volume_change, libmmc), Int32, (Ptr{Cvoid}, Float64, Float64),
                 b.h, new_box, new_kappa))
+
+"""
+    tot = volume_trial!(b, new_box, new_kappa); ...; volume_accept!(b) | volume_reject!(b)
+
+An NPT volume move of a ONE-replica batch without a host round trip (Ewald/volumeChange.jl:59-147):
+device-side snapshot, rescale, new tables, total energy at the new volume; a rejection restores
+everything bit for bit.
+"""
+function volume_trial!(b::Batch, new_box::Float64, new_kappa::Float64)
+    t = Ref{MMCTotals}()
+    check(ccall((:mmc_batch_volume_trial, libmmc), Int32, (Ptr{Cvoid}, Float64, Float64, Ptr{MMCTotals}),
+                b.h, new_box, new_kappa, t))
+    return t[]
+end
+volume_accept!(b::Batch) = check(ccall((:mmc_batch_volume_accept, libmmc), Int32, (Ptr{Cvoid},), b.h))
+volume_reject!(b::Batch) = check(ccall((:mmc_batch_volume_reject, libmmc), Int32, (Ptr{Cvoid},), b.h))
+
+"""
+    (run_stats, npt_stats) = run_npt!(b, params, npt, energy)
+
+An NPT chain of a one-replica batch: `npt.n_sweeps` times { `npt.moves_per_sweep` trial moves
+(Loop(), main.jl:487-644), one volume move (volumeChange.jl:59-147) }; `energy[1]` is the running
+total.energy of the replica.
+"""
+function run_npt!(b::Batch, params::MMCRunParams, npt::MMCNptParams, energy::Vector{Float64})
+    length(energy) == 1 || error("an NPT chain is a batch of one replica")
+    p = Ref(params); q = Ref(npt); st = Ref{MMCRunStats}(); ns = Ref{MMCNptStats}()
+    check(ccall((:mmc_batch_run_npt, libmmc), Int32,
+                (Ptr{Cvoid}, Ptr{MMCRunParams}, Ptr{MMCNptParams}, Ptr{Float64}, Ptr{MMCRunStats},
+                 Ptr{MMCNptStats}), b.h, p, q, energy, st, ns))
+    return st[], ns[]
+end
 
 # ---- the one collective of a sharded run: RCCL behind the C ABI (include/mmc_hip.h, mmc_dist_*) ----
 """

@@ -111,9 +111,11 @@ C2J = {
     "mmc_totals*": "Ptr{MMCTotals}", "mmc_move*": "Ptr{MMCMove}",
     "mmc_move_result*": "Ptr{MMCMoveResult}", "mmc_run_params*": "Ptr{MMCRunParams}",
     "mmc_run_stats*": "Ptr{MMCRunStats}", "mmc_chain*": "Ptr{MMCChain}",
+    "mmc_npt_params*": "Ptr{MMCNptParams}", "mmc_npt_stats*": "Ptr{MMCNptStats}",
 }
 C_STRUCT_OF = {"MMCTotals": "mmc_totals", "MMCMove": "mmc_move", "MMCMoveResult": "mmc_move_result",
-               "MMCRunParams": "mmc_run_params", "MMCRunStats": "mmc_run_stats", "MMCChain": "mmc_chain"}
+               "MMCRunParams": "mmc_run_params", "MMCRunStats": "mmc_run_stats", "MMCChain": "mmc_chain",
+               "MMCNptParams": "mmc_npt_params", "MMCNptStats": "mmc_npt_stats"}
 FIELD_C2J = {"double": "Float64", "int32_t": "Int32", "int64_t": "Int64", "uint64_t": "UInt64",
              "uint32_t": "UInt32"}
 SIZEOF = {"Float64": 8, "Int64": 8, "UInt64": 8, "Int32": 4, "UInt32": 4}
@@ -207,6 +209,8 @@ def test_every_ccall_matches_its_prototype():
     for sym in ("mmc_batch_create", "mmc_batch_destroy", "mmc_batch_eval", "mmc_batch_settle",
                 "mmc_batch_run", "mmc_batch_run_chains", "mmc_batch_potential_ewald",
                 "mmc_batch_recip_long", "mmc_batch_set_option", "mmc_batch_get_replica",
+                "mmc_batch_volume_trial", "mmc_batch_volume_accept", "mmc_batch_volume_reject",
+                "mmc_batch_run_npt",
                 "mmc_trial_move", "mmc_accept_move", "mmc_reject_move", "mmc_call_lj_poly_du",
                 "mmc_call_ewald_short", "mmc_call_ewald_real", "mmc_call_recip_move"):
         assert sym in bound, f"{sym} is not bound in MMCHip.jl"
@@ -289,7 +293,8 @@ def test_julia_structs_mirror_the_header_and_the_ctypes_mirrors():
     # sizes and a few offsets against the structures test_abi.py checks against gcc's layout
     for jname, ct in (("MMCTotals", _lib.Totals), ("MMCMove", _lib.Move),
                       ("MMCMoveResult", _lib.MoveResult), ("MMCRunParams", _lib.RunParams),
-                      ("MMCRunStats", _lib.RunStats)):
+                      ("MMCRunStats", _lib.RunStats), ("MMCNptParams", _lib.NptParams),
+                      ("MMCNptStats", _lib.NptStats)):
         offs, size = _layout(js[jname])
         assert size == C.sizeof(ct), jname
         for fname, _ in ct._fields_:
