@@ -338,12 +338,12 @@ __device__ __forceinline__ void total_wave_body(
         const int j_hi = j_chunk > 0 ? min(j_lo + j_chunk, n_mol) : n_mol;
         const int iA = j_chunk > 0 ? u / n_ch : u, iB = n_mol - 1 - u;
         const bool hasB = paired && iB > iA; // the middle molecule of an odd count stands alone
-        double wA = 0.0, wB = 0.0;
-        if (lane < MMC_REC) {
-            wA = myrec[(int64_t)iA * MMC_RSTRIDE + lane];
-            if (hasB)
-                wB = myrec[(int64_t)iB * MMC_RSTRIDE + lane];
-        }
+        // lane t < 12: word t of molecule A's record; lane 16 + t: word t of molecule B's
+        double wAB = 0.0;
+        if (lane < MMC_REC)
+            wAB = myrec[(int64_t)iA * MMC_RSTRIDE + lane];
+        else if (hasB && lane >= 16 && lane < 16 + MMC_REC)
+            wAB = myrec[(int64_t)iB * MMC_RSTRIDE + lane - 16];
 
         auto process = [&](int cnt) {
             wave_sync();
@@ -361,11 +361,11 @@ __device__ __forceinline__ void total_wave_body(
                     t[2 * q] = v.x;
                     t[2 * q + 1] = v.y;
                 }
-                // this lane's own molecule: a per-lane choice between two scalars
-                auto mine = [&](int word) {
-                    const double va = lane_f64(wA, word), vb = lane_f64(wB, word);
-                    return isB ? vb : va;
-                };
+                // this lane's own molecule: its words sit in lanes 0.. (A) or 16.. (B) of wAB -- one
+                // ds_bpermute pair per word with a per-lane source (two v_readlane pairs and a
+                // 64-bit select were 6 vector instructions per word, 72 per round of 64 neighbours)
+                const int own0 = isB ? 16 : 0;
+                auto mine = [&](int word) { return wave_pick(wAB, own0 + word); };
                 const double ccx = mine(9), ccy = mine(10), ccz = mine(11);
                 // the gate, exactly (energy.jl:248-254, ewalds.jl:334-340)
                 double m[3] = { 0, 0, 0 }; // (IMG) the image of this neighbour's molecule: 0 or +-1 per axis
@@ -438,12 +438,14 @@ __device__ __forceinline__ void total_wave_body(
         int cnt = 0;
         for (int half = 0; half < (hasB ? 2 : 1); half++) {
             const int i0 = half == 0 ? iA : iB;
-            const double w = half == 0 ? wA : wB;
+            const int woff = half == 0 ? 0 : 16;
             uint32_t cqxy, cqz; // this molecule's codes, x | y << 16 and z
             {
-                const int myq = (lane >= 9 && lane < 12) ? (int)com_quant(w, inv_box) : 0;
-                cqxy = (uint32_t)lane_i32(myq, 9) | (uint32_t)lane_i32(myq, 10) << 16;
-                cqz = (uint32_t)lane_i32(myq, 11);
+                const int t = lane & 15;
+                const int myq = (t >= 9 && t < 12) ? (int)com_quant(wAB, inv_box) : 0;
+                // (woff is wave-uniform, but not a constant: the lane index of v_readlane in an SGPR)
+                cqxy = (uint32_t)lane_i32(myq, woff + 9) | (uint32_t)lane_i32(myq, woff + 10) << 16;
+                cqz = (uint32_t)lane_i32(myq, woff + 11);
             }
             // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1, WV_TPF of
             // them per trip with no branch around a load (see mmc_wave_unit.inc); blocks past the

@@ -37,7 +37,12 @@ def pytest_configure(config):
             f"--master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --replicas 64 "
             f"{' '.join(common)} > {out}/two.json 2> {out}/two.err; echo $? > {out}/two.rc; "
             f"{sys.executable} bench.py --gpus 1 --replicas 128 {' '.join(common)} "
-            f"> {out}/one.json 2> {out}/one.err; echo $? > {out}/one.rc")
+            f"> {out}/one.json 2> {out}/one.err; echo $? > {out}/one.rc; "
+            # BASELINE configs[2]'s share of a GPU (32 chains) under two ranks: the move server
+            f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node 2 "
+            f"--master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --replicas 32 "
+            f"--steps 200 --warmup 20 --no-cpu --no-secondary --threads 2 "
+            f"> {out}/two32.json 2> {out}/two32.err; echo $? > {out}/two32.rc")
         proc = subprocess.Popen(["bash", "-c", script], env=env)
         config._mmc_dist = (proc, out)
 

@@ -49,6 +49,17 @@ def test_two_ranks_share_nothing_but_the_final_reduction(dist_rehearsal):
     assert abs(e2 - e1) < 1e-13 * abs(e1), (e2, e1)
 
 
+def test_two_ranks_of_32_chains_run_the_move_server(dist_rehearsal):
+    """BASELINE configs[2] is 256 chains over 8 GPUs = 32 per rank: that shape runs on the
+    persistent move server (host threads answering control words), here with two ranks at once."""
+    d = load(dist_rehearsal, "two32")
+    assert d["n_gpus"] == 2 and d["config"]["replicas_per_gpu"] == 32 and d["config"]["replicas_total"] == 64
+    assert "move server" in d["config"]["driver"]
+    assert d["energy_drift_rel"] < 1e-12 and d["torn_result_records"] == 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 * 200 - 64 * 200) < 1e-6 * 64 * 200
+    assert 0.5 < d["acceptance"] < 0.95
+
+
 def test_rccl_collective_behind_the_c_abi():
     """mmc_dist_*: the final reduction for hosts without torch.  A one-GPU box can form a
     communicator of ONE rank only (RCCL wants a GPU per rank): that still goes through
