@@ -937,3 +937,33 @@ def test_total_energy_kernels_of_large_batches(k, orc):
             S = b.get_replica(r)[2]
             assert np.abs(S - ew.sumQExpNew).max() < 1e-11 * np.abs(ew.sumQExpNew).max(), r
         assert np.array_equal(t["energy"][1:100], np.full(99, t["energy"][0]))
+
+
+@pytest.mark.parametrize("groups,threads", [(2, 2), (4, 3), (3, 1)])
+def test_stream_layout_does_not_change_the_chains(groups, threads):
+    """The driver's default with device-side proposals spreads the replica groups over two streams
+    (their launches overlap) and launches the first group's first step before its worker threads
+    exist; one stream runs every launch alone.  Chains are per-replica Markov chains: energies,
+    statistics, coordinates and S(k) must be IDENTICAL bit for bit whatever the layout, over
+    two calls in a row (the second continues streams, S-buffer parity and the proposal ring)."""
+    a = common.nist_arrays(4, "unwrapped")
+    R = 96
+    res = []
+    for n_streams in (0, 1, groups):
+        with make_batch(a, R) as b:
+            b.set_option("kernel", 2)
+            b.set_option("device_moves", 1)
+            b.set_option("persistent", 0)
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            stats = []
+            for n in (41, 23):
+                e, st = b.run(n, 298.15, 0.316555789, 0.05, seed=77, energies=e, n_groups=groups,
+                              n_parts=1, n_threads=threads, n_streams=n_streams)
+                stats.append([st[q] for q in ("moves", "trans_accept", "rot_accept", "overlaps", "launches")])
+            assert st["torn_records"] == 0
+            res.append((e.copy(), stats, [b.get_replica(r) for r in (0, R // 2, R - 1)]))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and res[0][1] == other[1]
+        for x, y in zip(res[0][2], other[2]):
+            assert all(np.array_equal(p, q) for p, q in zip(x, y))
+    assert res[0][1][0][0] == 41 * R and res[0][1][0][4] == 41 * groups
