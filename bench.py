@@ -615,12 +615,16 @@ def main():
     if os.environ.get("MMC_NO_PIN"):
         auto_threads = max(1, min(8, (len(affinity0) - local_world) // max(local_world, 1)))
     else:
-        n_dev = torch.cuda.device_count()
-        addrs = []
-        for k in range(local_world):
-            p_ = torch.cuda.get_device_properties(k % n_dev)
-            addrs.append((p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id))
-        pinned, auto_threads = _sh.pin_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")), addrs)
+        try:
+            n_dev = torch.cuda.device_count()
+            addrs = []
+            for k in range(local_world):
+                p_ = torch.cuda.get_device_properties(k % n_dev)
+                addrs.append((p_.pci_domain_id, p_.pci_bus_id, p_.pci_device_id))
+            pinned, auto_threads = _sh.pin_rank_to_gpu_numa(int(os.environ.get("LOCAL_RANK", "0")) % local_world, addrs)
+        except Exception as exc:   # placement is an optimisation: never the reason a run fails
+            print(f"bench.py: not pinning host threads ({exc!r})", file=sys.stderr)
+            auto_threads = max(1, min(8, (len(affinity0) - local_world) // max(local_world, 1)))
     if args.threads <= 0:
         args.threads = auto_threads
     torch.cuda.set_device(local_rank)
