@@ -103,6 +103,24 @@ def pmc_traffic(kernel, moves_per_launch):
                                    "command (committed); not measured in this run")
 
 
+def access_pattern_peak():
+    """(GB/s, microseconds per 32768-move launch, source) of scripts/gather_bw.hip: the move kernel's
+    memory access pattern -- COM-code stream, 125 scattered 128-byte record lines, S(k) read and
+    written, per unit, same launch shape -- replayed WITHOUT its arithmetic (committed under
+    profiles/; not measured in this run)."""
+    try:
+        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
+                      if p.endswith("_access_pattern_bw.json"))[-1]
+        t = json.load(open(os.path.join(ROOT, "profiles", path)))
+        c = next(c for c in t["cases"] if c["pattern"].startswith("the move kernel's mix"))
+        if int(t["units_per_launch"]) != 32768:
+            return None
+        return 1e3 * c["TB_per_s"], c["us_per_launch"], (f"profiles/{path}: scripts/gather_bw.hip, the kernel's loads and "
+                                                        "stores without its arithmetic (committed; not measured in this run)")
+    except (IndexError, OSError, ValueError, KeyError, StopIteration):
+        return None
+
+
 def pmc_extras(kernel, moves_per_launch):
     """What the committed rocprofv3 PMC passes of this command say beyond bytes (profiles/
     *_default_pmc_summary.json, written by scripts/summarize_profile.py): VALU instructions per
@@ -333,6 +351,10 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
             b["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
                         "bytes_per_move": traffic / moves_per_launch,
                         "frac_of_measured_copy_peak_6290": hb / 6290.0}
+            pat = access_pattern_peak()
+            if pat:   # what HBM delivers for THIS kernel's access pattern with no arithmetic at all
+                b["hbm"].update(pattern_peak=pat[0], frac_of_pattern_peak=hb / pat[0], pattern_floor_us=pat[1],
+                                pattern_source=pat[2])
         for k in ("lds_busy_frac", "lds_conflict_frac", "wait_frac", "salu_insts_per_move", "waves_per_simd"):
             if k in ex:
                 b[k] = ex[k]

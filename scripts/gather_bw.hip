@@ -1,0 +1,138 @@
+// gather_bw.hip -- what HBM delivers for the move kernel's ACCESS PATTERN, without its arithmetic.
+//
+//   hipcc --offload-arch=gfx950 -O3 -o build/gather_bw scripts/gather_bw.hip && build/gather_bw
+//
+// k_move_eval_wave moves 33.1 KB per trial move: 125 neighbour records gathered as 128-byte lines
+// scattered over the replica's 96 KB record array (16 KB), the replica's S(k) read (5.4 KB) and
+// written to its other buffer (5.4 KB), 4.5 KB of fixed-point centres of mass streamed, a move
+// record in and a result out.  Half of the bytes are 128-byte gathers: a stream copy's 6.29 TB/s
+// (MI355X_MICROARCH.md) is not the ceiling for that mix.  This program replays the pattern with the
+// same launch shape (1280 workgroups of 4 waves, persistent, one wave per "move", replicas of the
+// same sizes laid out the same way) and reports bytes / time:
+//   1. gathers only           random 128-B lines (6 x 16 B per lane, like the kernel's record loads)
+//   2. the kernel's mix       scan stream + gather + S read + S write per unit
+//   3. streams only           the same bytes with the gathers replaced by a contiguous read
+// Nothing here computes an energy; every loaded value is folded into a checksum so that no load is
+// dropped.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                                 \
+    do {                                                                                         \
+        hipError_t e_ = (x);                                                                     \
+        if (e_ != hipSuccess) {                                                                  \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                              \
+            exit(1);                                                                             \
+        }                                                                                        \
+    } while (0)
+
+constexpr int N_MOL = 750, N_NEIGH = 125, NK = 352;
+constexpr int64_t REC_DOUBLES = 16;                  // 128-byte records
+constexpr int64_t REP_REC = (int64_t)N_MOL * REC_DOUBLES; // doubles of records per replica
+constexpr int64_t REP_S = 2 * 2 * NK;                // two S buffers of NK complex doubles
+constexpr int64_t REP_CQ = 3 * 768;                  // 16-bit codes (x, y interleaved, then z), padded
+
+__device__ __forceinline__ uint32_t hash32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// mode bit 0: scan stream, bit 1: gather (bit 4: ... as a contiguous read instead), bit 2: S read,
+// bit 3: S write
+__global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, const uint16_t *cq,
+                                                 int n_units, int mode, unsigned salt, double *sink)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int unit = blockIdx.x * 4 + wv; unit < n_units; unit += gridDim.x * 4) {
+        const double *myrec = rec + (int64_t)unit * REP_REC;
+        double *myS = S + (int64_t)unit * REP_S;
+        if (mode & 1) { // the COM scan: 4 B (x, y) + 2 B (z) per molecule, 12 blocks of 64
+            const uint32_t *xy = reinterpret_cast<const uint32_t *>(cq + (int64_t)unit * REP_CQ);
+            const uint16_t *z = cq + (int64_t)unit * REP_CQ + 2 * 768;
+#pragma unroll
+            for (int b = 0; b < 12; b++)
+                acc += (double)(xy[64 * b + lane] ^ z[64 * b + lane]);
+        }
+        if (mode & 2) { // two rounds of 64 neighbours (125 of them), six 16-byte loads per record
+            for (int round = 0; round < 2; round++) {
+                const int n = 64 * round + lane;
+                int j = (mode & 16) ? n : (int)(hash32((unsigned)unit * 131u + (unsigned)n + salt) % N_MOL);
+                if (n >= N_NEIGH)
+                    j = (mode & 16) ? 0 : j; // (the kernel's idle lanes load molecule 0)
+                const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * REC_DOUBLES);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double2 v = src[q];
+                    acc += v.x + v.y;
+                }
+            }
+        }
+        if (mode & (4 | 8)) { // S_old read / S_new written: 337 complex doubles, lane per k
+            for (int k = lane; k < 337; k += 64) {
+                double2 v = make_double2(1.0, 2.0);
+                if (mode & 4)
+                    v = *reinterpret_cast<const double2 *>(myS + 2 * k);
+                if (mode & 8)
+                    *reinterpret_cast<double2 *>(myS + 2 * NK + 2 * k) = make_double2(v.x + 1.0, v.y);
+                else
+                    acc += v.x + v.y;
+            }
+        }
+    }
+    if (acc == 1.2345e300)
+        sink[0] = acc;
+}
+
+int main(int argc, char **argv)
+{
+    const int n_units = argc > 1 ? atoi(argv[1]) : 32768;
+    const int reps = argc > 2 ? atoi(argv[2]) : 40;
+    double *rec, *S, *sink;
+    uint16_t *cq;
+    // two "groups" of replicas, used alternately, like the bench (nothing stays in a cache between launches)
+    CHECK(hipMalloc(&rec, sizeof(double) * REP_REC * n_units * 2));
+    CHECK(hipMalloc(&S, sizeof(double) * REP_S * n_units * 2));
+    CHECK(hipMalloc(&cq, sizeof(uint16_t) * REP_CQ * n_units * 2 + 4096));
+    CHECK(hipMalloc(&sink, 64));
+    CHECK(hipMemset(rec, 0, sizeof(double) * REP_REC * n_units * 2));
+    CHECK(hipMemset(S, 0, sizeof(double) * REP_S * n_units * 2));
+    CHECK(hipMemset(cq, 0, sizeof(uint16_t) * REP_CQ * n_units * 2 + 4096));
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    struct Case { const char *name; int mode; double bytes_per_unit; };
+    const double gather_b = 125.0 * 128.0, scan_b = 750.0 * 6.0, s_b = 337.0 * 16.0;
+    const Case cases[] = {
+        { "gathers only (125 random 128-B lines per unit)", 2, gather_b },
+        { "the move kernel's mix: scan + gather + S read + S write", 1 | 2 | 4 | 8, scan_b + gather_b + 2 * s_b },
+        { "the same bytes, gathers as a contiguous read", 1 | 2 | 16 | 4 | 8, scan_b + gather_b + 2 * s_b },
+        { "scan + S read + S write only", 1 | 4 | 8, scan_b + 2 * s_b },
+    };
+    printf("{\"units_per_launch\": %d, \"launches_timed\": %d, \"cases\": [", n_units, reps);
+    bool first = true;
+    for (const Case &c : cases) {
+        for (int w = 0; w < 4; w++) // warm-up, both groups
+            k_pattern<<<1280, 256>>>(rec + (int64_t)(w & 1) * REP_REC * n_units, S + (int64_t)(w & 1) * REP_S * n_units,
+                                     cq + (int64_t)(w & 1) * REP_CQ * n_units, n_units, c.mode, 17u * w, sink);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < reps; i++)
+            k_pattern<<<1280, 256>>>(rec + (int64_t)(i & 1) * REP_REC * n_units, S + (int64_t)(i & 1) * REP_S * n_units,
+                                     cq + (int64_t)(i & 1) * REP_CQ * n_units, n_units, c.mode, 1000u + 31u * i, sink);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = 1e3 * ms / reps, tbs = c.bytes_per_unit * n_units / (us * 1e-6) / 1e12;
+        printf("%s{\"pattern\": \"%s\", \"bytes_per_unit\": %.0f, \"us_per_launch\": %.1f, \"TB_per_s\": %.3f}",
+               first ? "" : ", ", c.name, c.bytes_per_unit, us, tbs);
+        first = false;
+    }
+    printf("]}\n");
+    return 0;
+}
