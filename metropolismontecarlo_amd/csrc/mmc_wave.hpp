@@ -448,32 +448,41 @@ __device__ __forceinline__ void total_wave_body(
                 cqz = (uint32_t)lane_i32(myq, woff + 11);
             }
             // scan j > i0: 64-molecule blocks from the aligned block that holds i0 + 1, WV_TPF of
-            // them per trip with no branch around a load (see mmc_wave_unit.inc); blocks past the
-            // last molecule test clamped, masked lanes
-            int base = max(i0 + 1, j_lo) & ~63;
+            // them per trip with no branch around a load (see mmc_wave_unit.inc).  Addressing costs no
+            // vector instruction (scalar block pointers + lane offset + immediate) and nothing is
+            // clamped: the code arrays end in MMC_CQ_PAD readable bytes and what lies outside
+            // [first, j_hi) is masked by ONE unsigned compare of the lane's offset from `first`
+            // (this kernel is bound by vector issue, 0.81 busy: the three compares, two clamps and
+            // address arithmetic this replaces were 8 of a block's 25 vector instructions).
+            const int first = max(i0 + 1, j_lo);
+            int base = first & ~63;
+            const char *pxy = reinterpret_cast<const char *>(sxy) + 4 * (int64_t)base;
+            const char *pz = reinterpret_cast<const char *>(sz) + 2 * (int64_t)base;
+            const uint32_t ul4 = 4u * (uint32_t)lane, ul2 = 2u * (uint32_t)lane;
             uint32_t fxy[WV_TPF], fz[WV_TPF];
 #pragma unroll
             for (int b = 0; b < WV_TPF; b++) {
-                const int j = min(base + 64 * b + lane, n_mol - 1);
-                fxy[b] = sxy[j]; fz[b] = sz[j];
+                fxy[b] = *reinterpret_cast<const uint32_t *>(pxy + 256 * b + ul4);
+                fz[b] = *reinterpret_cast<const uint16_t *>(pz + 128 * b + ul2);
             }
             while (base < j_hi) {
 #pragma unroll
                 for (int b = 0; b < WV_TPF; b++) {
                     const int j = base + lane;
                     const uint32_t xy = fxy[b], z = fz[b];
-                    {
-                        const int jn = min(base + 64 * WV_TPF + lane, n_mol - 1);
-                        fxy[b] = sxy[jn]; fz[b] = sz[jn];
-                    }
-                    const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q) && (j < j_hi)
-                                      && (j > i0) && (j >= j_lo);
+                    fxy[b] = *reinterpret_cast<const uint32_t *>(pxy + 256 * (b + WV_TPF) + ul4);
+                    fz[b] = *reinterpret_cast<const uint16_t *>(pz + 128 * (b + WV_TPF) + ul2);
+                    // first <= j < j_hi  <=>  (unsigned)(j - first) < (unsigned)(j_hi - first)
+                    const bool keep = (com_quant_dist2(xy, z, cqxy, cqz) < gate_q)
+                                      && ((uint32_t)(j - first) < (uint32_t)(j_hi - first));
                     const unsigned long long m = wave_ballot(keep);
                     if (keep)
                         list[cnt + lanes_below(m)] = j | (half << 27);
                     cnt += __popcll(m);
                     base += 64;
                 }
+                pxy += 256 * WV_TPF;
+                pz += 128 * WV_TPF;
                 if (cnt > WV_LIST - 64 * WV_TPF) { // no room for another trip: empty the list
                     process(cnt);
                     cnt = 0;
