@@ -342,10 +342,11 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
     if ex.get("valu_insts_per_move") and ex.get("clock_ghz"):
         insts = ex["valu_insts_per_move"] * moves_per_launch / t_launch / 1e9   # G wave-instructions / s
         peak = N_SIMDS * ex["clock_ghz"] / 4.0
-        b = {"bound": "fp64_valu_issue", "achieved": insts, "peak": peak, "unit": "G wave64 instructions/s",
-             "frac": insts / peak, "valu_insts_per_move": ex["valu_insts_per_move"], "clock_ghz": ex["clock_ghz"],
-             "peak_is": f"{N_SIMDS} SIMDs x clock / 4 cycles per wave64 vector instruction (fp64 and fp32 alike)",
-             "counters_source": ex["counters_source"]}
+        valu = {"achieved": insts, "peak": peak, "unit": "G wave64 instructions/s", "frac": insts / peak,
+                "valu_insts_per_move": ex["valu_insts_per_move"], "clock_ghz": ex["clock_ghz"],
+                "peak_is": f"{N_SIMDS} SIMDs x clock / 4 cycles per wave64 vector instruction (fp64 and fp32 alike)"}
+        b = {"bound": "fp64_valu_issue", **{k: valu[k] for k in ("achieved", "peak", "unit", "frac")},
+             "fp64_valu_issue": valu, "counters_source": ex["counters_source"]}
         if traffic:
             hb = traffic / t_launch / 1e9
             b["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
@@ -355,6 +356,11 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
             if pat:   # what HBM delivers for THIS kernel's access pattern with no arithmetic at all
                 b["hbm"].update(pattern_peak=pat[0], frac_of_pattern_peak=hb / pat[0], pattern_floor_us=pat[1],
                                 pattern_source=pat[2])
+                if hb / pat[0] > valu["frac"]:   # the larger fraction names the bound
+                    b.update(bound="hbm_access_pattern", achieved=hb, peak=pat[0], unit="GB/s", frac=hb / pat[0],
+                             peak_is="counter bytes of the kernel against what its own loads and stores reach "
+                                     "with the arithmetic removed (scripts/gather_bw.hip: code stream, scattered "
+                                     "128-byte record lines, S(k) read and written; same launch shape)")
         for k in ("lds_busy_frac", "lds_conflict_frac", "wait_frac", "salu_insts_per_move", "waves_per_simd"):
             if k in ex:
                 b[k] = ex[k]
@@ -797,6 +803,7 @@ def main():
                     "avg_launch_us_is": rf1["avg_launch_us_is"] if rf1 else None,
                     "frac": rf1["frac"] if rf1 else None,
                     "binding_frac": rf1.get("binding", {}).get("frac") if rf1 else None,
+                    "binding_bound": rf1.get("binding", {}).get("bound") if rf1 else None,
                     "energy_drift_rel": r_["drift"],
                     "note": "every launch alone on the GPU: its HIP-event duration is its cost and is what "
                             "rocprofv3 --kernel-trace reports for `--streams 1` (profiles/)"}

@@ -51,6 +51,16 @@ __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, c
     for (int unit = blockIdx.x * 4 + wv; unit < n_units; unit += gridDim.x * 4) {
         const double *myrec = rec + (int64_t)unit * REP_REC;
         double *myS = S + (int64_t)unit * REP_S;
+        if (mode & 32) { // (experiment) the same 4.5 KB of codes with 16-byte and 8-byte loads per lane
+            const uint4 *xy4 = reinterpret_cast<const uint4 *>(cq + (int64_t)unit * REP_CQ);
+            const uint2 *z4 = reinterpret_cast<const uint2 *>(cq + (int64_t)unit * REP_CQ + 2 * 768);
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const uint4 v = xy4[64 * b + lane];
+                const uint2 w = z4[64 * b + lane];
+                acc += (double)(v.x ^ v.y ^ v.z ^ v.w ^ w.x ^ w.y);
+            }
+        } else
         if (mode & 1) { // the COM scan: 4 B (x, y) + 2 B (z) per molecule, 12 blocks of 64
             const uint32_t *xy = reinterpret_cast<const uint32_t *>(cq + (int64_t)unit * REP_CQ);
             const uint16_t *z = cq + (int64_t)unit * REP_CQ + 2 * 768;
@@ -112,6 +122,10 @@ int main(int argc, char **argv)
         { "the move kernel's mix: scan + gather + S read + S write", 1 | 2 | 4 | 8, scan_b + gather_b + 2 * s_b },
         { "the same bytes, gathers as a contiguous read", 1 | 2 | 16 | 4 | 8, scan_b + gather_b + 2 * s_b },
         { "scan + S read + S write only", 1 | 4 | 8, scan_b + 2 * s_b },
+        { "(experiment) the mix with the codes read by 16- and 8-byte loads", 32 | 2 | 4 | 8, scan_b + gather_b + 2 * s_b },
+        { "(experiment) scan only, 4- and 2-byte loads", 1, scan_b },
+        { "(experiment) scan only, 16- and 8-byte loads", 32, scan_b },
+        { "(experiment) S read + S write only", 4 | 8, 2 * s_b },
     };
     printf("{\"units_per_launch\": %d, \"launches_timed\": %d, \"cases\": [", n_units, reps);
     bool first = true;

@@ -124,6 +124,38 @@ if bench.get("roofline") and bench["roofline"].get("kernel") == KERNEL:
     bench["roofline"]["traffic_source"] = (f"profiles/{TAG}_traffic.json: the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                            "passes of the same profiling session (scripts/profile_round.sh); "
                                            "filled in by scripts/summarize_profile.py, not measured by this run")
+    # ... and `binding` from this session's counters (the run quoted the previous profile's)
+    rf = bench["roofline"]
+    t = rf["avg_launch_us"] * 1e-6
+    mpl = rf["moves_per_launch"]
+    src = (f"profiles/{TAG}_default_pmc_summary.json (rocprofv3 --pmc passes of the same profiling session; "
+           "filled in by scripts/summarize_profile.py, not measured by this run)")
+    pat = os.path.join(ROOT, "gpurun_out", "gather_bw.json")
+    if os.path.exists(pat):
+        shutil.copy(pat, os.path.join(DST, f"{TAG}_access_pattern_bw.json"))
+    # recompute with bench.py's own code, which now finds this session's files under profiles/
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench as bench_mod
+    args = argparse.Namespace(kernel=3, no_events=False)
+    def again(r, streams, elapsed_us_per_launch):
+        st = {"launches": r["launches"], "moves": r["moves_per_launch"] * r["launches"],
+              "timed_launches": r["launches_timed_with_events"],
+              "kernel_ms": (r.get("launch_span_us") or r["avg_launch_us"]) * 1e-3 * r["launches_timed_with_events"]}
+        res = {"st": st, "elapsed": elapsed_us_per_launch * 1e-6 * r["launches"], "streams": streams}
+        return bench_mod.roofline_object(res, bench["config"]["replicas_per_gpu"], args,
+                                         {"groups": bench["config"]["groups_per_gpu"]}, 750, 30.0, 1)
+    new = again(rf, bench["config"].get("streams_per_gpu", 1), rf["avg_launch_us"])
+    if new and "binding" in new:
+        rf["binding"] = new["binding"]
+        rf["binding"]["counters_source"] = src
+        one = bench.get("one_stream")
+        if one and one.get("avg_launch_us"):
+            b1 = dict(rf)
+            b1.update(avg_launch_us=one["avg_launch_us"], launch_span_us=one["avg_launch_us"])
+            n1 = again(b1, 1, one["avg_launch_us"])
+            if n1 and "binding" in n1:
+                one["binding_frac"], one["binding_bound"] = n1["binding"]["frac"], n1["binding"]["bound"]
     json.dump(bench, open(os.path.join(DST, f"{TAG}_default_bench.json"), "w"))
 # ---- the persistent move server of one chain (BASELINE configs[1]): counters of its longest dispatch
 def server_summary():
