@@ -77,7 +77,13 @@ __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, c
                 const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * REC_DOUBLES);
 #pragma unroll
                 for (int q = 0; q < 6; q++) {
-                    const double2 v = src[q];
+                    double2 v;
+                    if (mode & 128) {
+                        v.x = __builtin_nontemporal_load(&src[q].x);
+                        v.y = __builtin_nontemporal_load(&src[q].y);
+                    } else {
+                        v = src[q];
+                    }
                     acc += v.x + v.y;
                 }
             }
@@ -85,9 +91,18 @@ __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, c
         if (mode & (4 | 8)) { // S_old read / S_new written: 337 complex doubles, lane per k
             for (int k = lane; k < 337; k += 64) {
                 double2 v = make_double2(1.0, 2.0);
-                if (mode & 4)
-                    v = *reinterpret_cast<const double2 *>(myS + 2 * k);
-                if (mode & 8)
+                if (mode & 4) {
+                    if (mode & 128) {
+                        v.x = __builtin_nontemporal_load(myS + 2 * k);
+                        v.y = __builtin_nontemporal_load(myS + 2 * k + 1);
+                    } else {
+                        v = *reinterpret_cast<const double2 *>(myS + 2 * k);
+                    }
+                }
+                if ((mode & 8) && (mode & 64)) {
+                    __builtin_nontemporal_store(v.x + 1.0, myS + 2 * NK + 2 * k);
+                    __builtin_nontemporal_store(v.y, myS + 2 * NK + 2 * k + 1);
+                } else if (mode & 8)
                     *reinterpret_cast<double2 *>(myS + 2 * NK + 2 * k) = make_double2(v.x + 1.0, v.y);
                 else
                     acc += v.x + v.y;
@@ -126,6 +141,9 @@ int main(int argc, char **argv)
         { "(experiment) scan only, 4- and 2-byte loads", 1, scan_b },
         { "(experiment) scan only, 16- and 8-byte loads", 32, scan_b },
         { "(experiment) S read + S write only", 4 | 8, 2 * s_b },
+        { "(experiment) the mix, S written with nontemporal stores", 1 | 2 | 4 | 8 | 64, scan_b + gather_b + 2 * s_b },
+        { "(experiment) the mix, nontemporal loads (gather, S) and stores", 1 | 2 | 4 | 8 | 64 | 128, scan_b + gather_b + 2 * s_b },
+        { "(experiment) S read + S write only, nontemporal both", 4 | 8 | 64 | 128, 2 * s_b },
     };
     printf("{\"units_per_launch\": %d, \"launches_timed\": %d, \"cases\": [", n_units, reps);
     bool first = true;
