@@ -42,9 +42,12 @@ __device__ __forceinline__ uint32_t hash32(uint32_t x)
 }
 
 // mode bit 0: scan stream, bit 1: gather (bit 4: ... as a contiguous read instead), bit 2: S read,
-// bit 3: S write
+// bit 3: S write, bit 5: codes by wide loads, bit 6: nontemporal S stores, bit 7: nontemporal loads
+// (the mode is a template parameter: a run-time test of it around a load makes the compiler wait for
+// every outstanding load at each use -- the "gathers only" case ran 97 instead of 81 us that way)
+template <int mode>
 __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, const uint16_t *cq,
-                                                 int n_units, int mode, unsigned salt, double *sink)
+                                                 int n_units, unsigned salt, double *sink)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc = 0.0;
@@ -147,15 +150,26 @@ int main(int argc, char **argv)
     };
     printf("{\"units_per_launch\": %d, \"launches_timed\": %d, \"cases\": [", n_units, reps);
     bool first = true;
+    auto launch = [&](int mode, int grp, unsigned salt) {
+        const double *r_ = rec + (int64_t)grp * REP_REC * n_units;
+        double *s_ = S + (int64_t)grp * REP_S * n_units;
+        const uint16_t *c_ = cq + (int64_t)grp * REP_CQ * n_units;
+#define MODE_CASE(M) case M: k_pattern<M><<<1280, 256>>>(r_, s_, c_, n_units, salt, sink); break;
+        switch (mode) {
+            MODE_CASE(2) MODE_CASE(1 | 2 | 4 | 8) MODE_CASE(1 | 2 | 16 | 4 | 8) MODE_CASE(1 | 4 | 8)
+            MODE_CASE(32 | 2 | 4 | 8) MODE_CASE(1) MODE_CASE(32) MODE_CASE(4 | 8)
+            MODE_CASE(1 | 2 | 4 | 8 | 64) MODE_CASE(1 | 2 | 4 | 8 | 64 | 128) MODE_CASE(4 | 8 | 64 | 128)
+        default: fprintf(stderr, "mode %d not instantiated\n", mode); exit(1);
+        }
+#undef MODE_CASE
+    };
     for (const Case &c : cases) {
         for (int w = 0; w < 4; w++) // warm-up, both groups
-            k_pattern<<<1280, 256>>>(rec + (int64_t)(w & 1) * REP_REC * n_units, S + (int64_t)(w & 1) * REP_S * n_units,
-                                     cq + (int64_t)(w & 1) * REP_CQ * n_units, n_units, c.mode, 17u * w, sink);
+            launch(c.mode, w & 1, 17u * w);
         CHECK(hipDeviceSynchronize());
         CHECK(hipEventRecord(e0));
         for (int i = 0; i < reps; i++)
-            k_pattern<<<1280, 256>>>(rec + (int64_t)(i & 1) * REP_REC * n_units, S + (int64_t)(i & 1) * REP_S * n_units,
-                                     cq + (int64_t)(i & 1) * REP_CQ * n_units, n_units, c.mode, 1000u + 31u * i, sink);
+            launch(c.mode, i & 1, 1000u + 31u * i);
         CHECK(hipEventRecord(e1));
         CHECK(hipEventSynchronize(e1));
         float ms = 0.f;
