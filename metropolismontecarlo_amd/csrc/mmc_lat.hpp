@@ -223,7 +223,7 @@ __global__ __launch_bounds__(LAT_WAVES * 64, 2) void k_move_eval_lat(
         lat_store_combined<false>(ls, out + (int64_t)r * (n_parts / LAT_WAVES) + g, lane, stamp);
 }
 
-// Diagnostic build (-DLAT_PROFILE, scripts/dev_lat_profile.py): every wave of replica 0 sums the
+// Diagnostic build (-DLAT_PROFILE, scripts/lat_profile.py): every wave of replica 0 sums the
 // 10 ns ticks it spends per phase of a step -- waiting for the word, commit, unit body, barrier +
 // record, next proposal -- read back with mmc_debug_lat_profile.  Compiled out of the product.
 #ifdef LAT_PROFILE
