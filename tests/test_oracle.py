@@ -283,3 +283,32 @@ def test_wolf_prefactor_closed_form():
     fast = orc.potential_wolf(s, ew, RCUT, RCUT, literal_prefactor=False)
     assert rel(lit["energy"], fast["energy"]) < 1e-13
     assert lit["virial"] == fast["virial"]
+
+
+def test_kx0_plane_of_the_structure_factor_comes_in_exact_conjugate_pairs():
+    """The reference keeps BOTH (0, ky, kz) and (0, -ky, -kz) (ewalds.jl:57-89 halves only kx > 0 by
+    doubling cfac): 88 of the 337 k-vectors, 44 pairs.  Its phase tables take negative indices as
+    conjugates (ewalds.jl:575-585, :781-796), and products and sums of conjugates are conjugates
+    bit for bit in IEEE arithmetic: S(0,-ky,-kz) == conj(S(0,ky,kz)) EXACTLY, after RecipLong and
+    after every RecipMove.  (the 13 % of S(k) traffic a layout without the
+    redundant half would save.)"""
+    from oracle import oracle as orc
+    a = common.nist_arrays(2, "unwrapped")
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    k = ew.kxyz.tolist()
+    idx = {tuple(v): i for i, v in enumerate(k)}
+    pairs = [(i, idx[(0, -v[1], -v[2])]) for i, v in enumerate(k) if v[0] == 0 and idx[(0, -v[1], -v[2])] > i]
+    assert len(pairs) == 44 and sum(v[0] == 0 for v in k) == 88
+
+    def exact(S):
+        return all(S[j].real == S[i].real and S[j].imag == -S[i].imag for i, j in pairs)
+    assert exact(ew.sumQExpNew) and exact(ew.sumQExpOld)
+    assert all(ew.cfac[i] == ew.cfac[j] for i, j in pairs)
+    rng = np.random.default_rng(3)
+    for m in (1, 57, 200):
+        d = (rng.random(3) - 0.5) * 0.3
+        orc.trial_move(m, s, ew, 10.0, 10.0, s.com[m - 1] + d, s.coords[3 * m - 3:3 * m] + d)
+        assert exact(ew.sumQExpNew)
+        ew.sumQExpOld = ew.sumQExpNew.copy()
