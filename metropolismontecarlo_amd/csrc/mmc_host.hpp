@@ -72,7 +72,12 @@ struct DeviceSystem {
     RecipOrder recip_order;        // its (kx, ky) columns, most work first (prepare_ewald)
     double c_sq = 0.0, c_sq2 = 0.0;
     bool fast_table_ok(double qq_rcut) const; // the erfc table covers this cutoff
-    int64_t nk = 0, k_sq_max = 0, nkvecs = 0;
+    int64_t nk = 0, k_sq_max = 0;
+    int64_t nkvecs = 0;     // k-vectors the device holds (= bv.nkvecs)
+    int64_t nkvecs_ref = 0; // ... and the reference's NKVECS (ewalds.jl:90): the same unless half_k
+    bool half_k = false;    // keep one of each conjugate pair of the kx = 0 plane (k_kvec_setup); set before prepare_ewald
+    std::vector<int32_t> ref_to_dev; // [nkvecs_ref] device index, or ~index of the conjugate partner
+    void expand_S(const double *dev_order, double *ref_order) const;
     BatchView bv{};
     std::vector<void *> allocs; // hipMalloc'ed
     std::vector<int32_t> h_first0, h_cnt;

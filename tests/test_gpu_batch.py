@@ -967,3 +967,53 @@ def test_stream_layout_does_not_change_the_chains(groups, threads):
         for x, y in zip(res[0][2], other[2]):
             assert all(np.array_equal(p, q) for p, q in zip(x, y))
     assert res[0][1][0][0] == 41 * R and res[0][1][0][4] == 41 * groups
+
+
+def test_half_space_k_list_gives_the_reference_structure_factor(orc):
+    """A batch keeps 293 of the reference's 337 k-vectors: of each conjugate pair (0, ky, kz) /
+    (0, -ky, -kz) the first, with twice the weight (k_kvec_setup).  mmc_batch_get_replica hands
+    the reference's array back; checked here against the oracle's sumQExp -- all 337 entries --
+    and against the same batch run with the full list (MMC_FULL_K): the same chains (accept
+    counts, coordinates, S(k) bit for bit), energies that differ by the order of a 337- / 293-term
+    sum only."""
+    import os
+    a = common.nist_arrays(4, "unwrapped")
+    R = 64
+    s = common.oracle_system(a)
+    ew = orc.Ewald(5.6 / s.box, 5, 27, s.box)
+    orc.recip_long(ew, s.coords, s.charge, s.box)
+    kx0 = [i for i, v in enumerate(ew.kxyz.tolist()) if v[0] == 0]
+    assert len(ew.kxyz) == 337 and len(kx0) == 88
+    out = {}
+    for full in (False, True):
+        if full:
+            os.environ["MMC_FULL_K"] = "1"
+        try:
+            with make_batch(a, R) as b:
+                b.set_option("kernel", 2)
+                b.set_option("device_moves", 1)
+                t0 = b.potential_ewald(as_array=True)
+                S0 = b.get_replica(R - 1)[2]
+                e, st = b.run(60, 298.15, 0.316555789, 0.05, seed=5, energies=t0["energy"].copy(),
+                              n_groups=2, n_parts=1, n_threads=2)
+                out[full] = (t0["recip"].copy(), S0, e.copy(),
+                             [st[q] for q in ("moves", "trans_accept", "rot_accept", "overlaps")],
+                             [b.get_replica(r) for r in (0, R - 1)], b.potential_ewald(as_array=True)["energy"].copy())
+        finally:
+            os.environ.pop("MMC_FULL_K", None)
+    half, full = out[False], out[True]
+    assert np.abs(half[1] - ew.sumQExpNew).max() < 1e-11 * np.abs(ew.sumQExpNew).max()
+    assert np.array_equal(half[1], full[1])                    # S(k) after RecipLong, 337 entries
+    to = orc.potential_ewald(common.oracle_system(a), orc.Ewald(5.6 / s.box, 5, 27, s.box), RCUT, RCUT)
+    assert rel(half[0][0], to["recip"]) < 1e-12
+    assert np.abs(half[0] - full[0]).max() < 1e-13 * np.abs(full[0]).max()
+    assert half[3] == full[3] and half[3][0] == 60 * R         # the same chains
+    for x, y in zip(half[4], full[4]):
+        assert all(np.array_equal(p, q) for p, q in zip(x, y))
+        S = x[2]
+        pairs = {tuple(v): i for i, v in enumerate(ew.kxyz.tolist())}
+        for i in kx0:                                          # exact conjugates, as in the reference
+            j = pairs[(0, -ew.kxyz[i][1], -ew.kxyz[i][2])]
+            assert S[j].real == S[i].real and S[j].imag == -S[i].imag
+    assert np.abs(half[2] - full[2]).max() < 1e-12 * np.abs(full[2]).max()
+    assert np.abs(half[2] - half[5]).max() < 1e-11 * np.abs(half[5]).max()   # running = recomputed
