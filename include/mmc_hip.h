@@ -316,6 +316,20 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      number; same move distributions as the host generator, a different random
  *                      stream): only one flag byte per replica and step crosses PCIe and no host
  *                      mirror of the coordinates is kept.  Default 0.
+ *   "accept_on_device" who makes the Metropolis decision of a step of mmc_batch_run / _run_chains:
+ *                      1 = the move kernel itself, where it can (device_moves, one part per move,
+ *                      the wave kernel, no step-size adaptation): Metropolis(dU / T) && !overlap with
+ *                      the same Philox uniform the host would take, its S-buffer bit and accept flag
+ *                      kept in device memory for the next launch's commit, the decision sent along
+ *                      in the result record (bit 31 of the stamp word) for the host's bookkeeping --
+ *                      the same chains bit for bit, and a launch does not wait for the host's pass
+ *                      over the previous launch's records.  0 = the host (its threads read every
+ *                      record, decide, and write a flag byte per replica before the next launch:
+ *                      ~50 ns per record and thread, hidden behind the other group's kernel while
+ *                      there are about 8 threads per 32768-move launch).  -1 (default) = 1 where a
+ *                      host thread would have more than 4096 records per launch to decide, else 0
+ *                      (with eight or more threads per 32768 moves the host's decision costs the
+ *                      kernel nothing and measures 1-2 % faster).
  *   "image_by_molecule" -1 (default) = the wave kernel takes the minimum image of an atom pair with
  *                      the image of its molecule's centre of mass where that is the reference's
  *                      vector1D bit for bit: moves made on the device (rigid), and
@@ -442,6 +456,8 @@ typedef struct {
                                checksum when first read (re-read until whole) */
     int64_t server_steps;   /* steps that ran on the persistent move server (option "persistent"):
                                `launches` then counts control-word posts, not kernel launches */
+    int64_t device_decisions; /* moves whose accept decision the move kernel made itself (option
+                               "accept_on_device"): the host did their bookkeeping only */
 } mmc_run_stats;
 
 /* An NPT chain of a one-replica batch: n_sweeps times { moves_per_sweep trial moves (mmc_batch_run:

@@ -61,7 +61,7 @@ class RunStats(C.Structure):
                 ("rot_accept", C.c_int64), ("overlaps", C.c_int64), ("wall_ms", C.c_double),
                 ("kernel_ms", C.c_double), ("energy_sum", C.c_double),
                 ("timed_launches", C.c_int64), ("torn_records", C.c_int64),
-                ("server_steps", C.c_int64)]
+                ("server_steps", C.c_int64), ("device_decisions", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -418,12 +418,40 @@ __device__ __forceinline__ uint32_t part_checksum_lanes(double word, int lane, u
 }
 
 // word 7 of the record: ovl[0] = checksum << 1 | overlap_old, ovl[1] = stamp << 1 | overlap_new
-__device__ inline double pack_ovl(int o0, int o1, unsigned stamp, uint32_t csum)
+// (bit 31 of ovl[1]: the Metropolis decision, where the kernel made it -- DecideConsts below)
+__device__ inline double pack_ovl(int o0, int o1, unsigned stamp, uint32_t csum, int accept = 0)
 {
     const unsigned lo = (csum << 1) | (unsigned)(o0 & 1),
-                   hi = ((stamp & MMC_STAMP_MASK) << 1) | (unsigned)(o1 & 1);
+                   hi = ((unsigned)(accept & 1) << 31) | ((stamp & MMC_STAMP_MASK) << 1) | (unsigned)(o1 & 1);
     return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
+__host__ __device__ inline uint32_t part_stamp_of(int32_t ovl1) { return ((uint32_t)ovl1 >> 1) & MMC_STAMP_MASK; }
+__host__ __device__ inline int part_accept_of(int32_t ovl1) { return (int)((uint32_t)ovl1 >> 31); }
+
+// dU of a move from the seven sums of its ONE result record, in mmc_combine_parts' arithmetic
+// (mmc_system.inc; main.jl:574-593): the number Metropolis() is called with.  On the host and on
+// the device, -ffp-contract=off on both: the same bits.
+__host__ __device__ inline double mmc_move_delta(const double *w7, bool ov_old, bool ov_new, double factor)
+{
+    const double e0 = (0.0 + w7[0]) * 4, e1 = (0.0 + w7[1]) * 4;       // energy.jl:289
+    double q0 = ov_old ? 0.0 : 0.0 + w7[4], q1 = ov_new ? 0.0 : 0.0 + w7[5]; // ewalds.jl:359-360
+    q0 *= factor; q1 *= factor;                                         // ewalds.jl:905
+    const double d_recip = (ov_old || ov_new) ? 0.0 : (0.0 + w7[6]) * factor; // main.jl:580-590
+    return ((e1 - e0) + (q1 - q0)) + d_recip;                           // main.jl:593
+}
+
+// The accept decision made by the kernel that evaluated the move (launches of one part per move,
+// device-side proposals): Metropolis(dU / T) && !overlap (main.jl:598, auxillary.jl:106-114) with
+// the step's uniform from the chain's Philox counter (mmc_propose.hpp) -- what Driver::decide does
+// on the host, without the trip there and back between two steps of a chain.  The kernel rewrites
+// the replica's flag byte (accept | S-buffer << 1) for the NEXT launch's commit and sends the
+// decision to the host in its result record, which the host uses for its bookkeeping as it is.
+struct DecideConsts {
+    double temperature, factor;
+    uint64_t seed;
+    uint32_t replica0, _pad;
+    uint8_t *flags; // [R]
+};
 
 // grid (n_parts, R).  n_parts == 1: the workgroup scans all molecules and then does the
 // reciprocal part.  n_parts > 1: parts 0..n_parts-2 split the molecule range, the last part does

@@ -133,6 +133,30 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
     }
 }
 
+// The kernel's own Metropolis decision (DecideConsts, mmc_kernels.hpp): every lane computes it from
+// the unit's seven sums in LDS; lane 0 rewrites the replica's flag byte.  Returns accept (0 / 1).
+__device__ __forceinline__ int wave_decide(const double *outw, bool ov_old, bool ov_new,
+                                           const DecideConsts *__restrict__ dc, long long step, int r,
+                                           int scur, int lane)
+{
+    const double delta = mmc_move_delta(outw, ov_old, ov_new, dc->factor);
+    const double x = delta / dc->temperature;
+    const double u = mmc_metropolis_uniform(ChainKey{ dc->seed, dc->replica0 + (uint32_t)r }, (uint64_t)step);
+    // exp(-x) > u, decided without the exponential where 1 - x <= exp(-x) <= 1 / (1 + x) (x >= 0)
+    // already says which (the margins are far above the rounding of the two bounds): every lane of
+    // the wave holds the same x, so these are branches, and exp() -- ~50 fp64 instructions that
+    // cost the SIMD the same for one lane as for 64 -- runs for about a third of the moves.
+    bool met;
+    if (x < 0.0) met = true;
+    else if (1.0 - x > u + 1e-9) met = true;
+    else if ((1.0 + x) * u > 1.0 + 1e-9) met = false;
+    else met = exp(-x) > u;
+    const int acc = (met && !(ov_old || ov_new)) ? 1 : 0;
+    if (lane == 0)
+        dc->flags[r] = (uint8_t)(acc | ((scur ^ acc) << 1));
+    return acc;
+}
+
 // grid: any number of workgroups of WV_WAVES waves; wave w of workgroup g handles units
 // g * WV_WAVES + w, + gridDim.x * WV_WAVES, ...  Unit u = (replica r_base + u / n_parts,
 // part u % n_parts); part semantics as k_move_eval (the last part of n_parts > 1 does the
@@ -147,7 +171,7 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
     const MoveRec *__restrict__ prev, PartOut *out, int n_parts, PairParams pp, int r_base,
-    int n_units, const uint8_t *__restrict__ flagv, unsigned stamp)
+    int n_units, const uint8_t *flagv, unsigned stamp, const DecideConsts *__restrict__ dc, long long dec_step)
 {
     __shared__ __align__(16) WaveSharedT<WV_MWAVES> sm;
     const int tid = threadIdx.x, lane0 = tid & 63;
@@ -242,6 +266,7 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
         // (expanded where they are used: as variables they would be live across the whole unit)
 #define WV_CQ_BASE (bv.comq + (int64_t)r * 3 * bv.cq_stride)
 #define WV_PART_DST (out + (int64_t)r * n_parts + part)
+#define WV_DECIDE(o0, o1) (dc ? wave_decide(outw, o0, o1, dc, dec_step, r, scur, lane) : 0)
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
 #define WV_IMG IMG
@@ -264,6 +289,7 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #undef WV_ZERO
 #undef WV_CQ_BASE
 #undef WV_PART_DST
+#undef WV_DECIDE
     }
 }
 

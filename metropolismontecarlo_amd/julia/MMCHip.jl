@@ -119,7 +119,7 @@ struct MMCRunStats
     moves::Int64; launches::Int64
     trans_attempt::Int64; trans_accept::Int64; rot_attempt::Int64; rot_accept::Int64; overlaps::Int64
     wall_ms::Float64; kernel_ms::Float64; energy_sum::Float64
-    timed_launches::Int64; torn_records::Int64; server_steps::Int64
+    timed_launches::Int64; torn_records::Int64; server_steps::Int64; device_decisions::Int64
 end
 
 struct MMCNptParams

@@ -57,7 +57,7 @@ def test_struct_layouts_match_header(tmp_path):
         'printf("%zu %zu %zu\\n", sizeof(mmc_move), offsetof(mmc_move, com_new), offsetof(mmc_move, atoms_new));\n'
         'printf("%zu %zu\\n", sizeof(mmc_move_result), sizeof(mmc_totals));\n'
         'printf("%zu %zu %zu\\n", sizeof(mmc_run_params), offsetof(mmc_run_params, n_streams), offsetof(mmc_run_params, replica0));\n'
-        'printf("%zu %zu %zu\\n", sizeof(mmc_run_stats), offsetof(mmc_run_stats, timed_launches), offsetof(mmc_run_stats, server_steps));\n'
+        'printf("%zu %zu %zu\\n", sizeof(mmc_run_stats), offsetof(mmc_run_stats, timed_launches), offsetof(mmc_run_stats, device_decisions));\n'
         'printf("%zu %zu\\n", sizeof(mmc_chain), offsetof(mmc_chain, trans_set_value));\n'
         "return 0;}\n")
     exe = tmp_path / "layout"
@@ -70,7 +70,7 @@ def test_struct_layouts_match_header(tmp_path):
     assert rows[2] == [C.sizeof(_lib.RunParams), _lib.RunParams.n_streams.offset,
                        _lib.RunParams.replica0.offset]
     assert rows[3] == [C.sizeof(_lib.RunStats), _lib.RunStats.timed_launches.offset,
-                       _lib.RunStats.server_steps.offset]
+                       _lib.RunStats.device_decisions.offset]
     assert rows[4] == [_lib.CHAIN_DTYPE.itemsize, _lib.CHAIN_DTYPE.fields["trans_set_value"][1]]
     assert rows[4][0] == 144                       # mmc_chain: 18 eight-byte fields
 

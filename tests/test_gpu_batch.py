@@ -665,13 +665,14 @@ def _rigid_proposal(seed, replica, step, com, atoms, box, dr_max, dphi_max):
     return 1, com.copy(), com + (atoms - com) @ Rm.T, u_met
 
 
-@pytest.mark.parametrize("kernel,R,parts", [(2, 24, 1), (1, 2, 0), (4, 1, 16)])
-def test_driver_device_moves_stepped_by_the_oracle(kernel, R, parts, orc):
+@pytest.mark.parametrize("kernel,R,parts,on_device", [(2, 24, 1, 0), (2, 24, 1, 1), (1, 2, 0, 0), (4, 1, 16, 0)])
+def test_driver_device_moves_stepped_by_the_oracle(kernel, R, parts, on_device, orc):
     """mmc_batch_run with device-side proposals at 750 molecules, every step checked: the oracle
     steps the same chains -- proposal rebuilt from the exported Philox draws, dU from
     orc.trial_move, Metropolis (auxillary.jl:106-114) with the step's own uniform -- and the
     driver's recorded dU and decision of EVERY step (option "trace_steps"), accepted or
-    rejected, must agree: a wrong dU on a rejected move cannot hide in the final state."""
+    rejected, must agree: a wrong dU on a rejected move cannot hide in the final state.
+    on_device = 1: the decisions are the move kernel's own (option "accept_on_device")."""
     import math
     a = common.nist_arrays(4, "unwrapped")
     n_mol, box = a["com"].shape[0], a["box"]
@@ -681,10 +682,12 @@ def test_driver_device_moves_stepped_by_the_oracle(kernel, R, parts, orc):
         b.set_option("kernel", kernel)
         b.set_option("device_moves", 1)
         b.set_option("persistent", 0 if kernel != 4 else 1)   # launch per step; the latency server
+        b.set_option("accept_on_device", on_device)
         b.set_option("trace_steps", n_steps)
         e0 = b.potential_ewald(as_array=True)["energy"].copy()
         e1, st = b.run(n_steps, T, dr, dphi, seed=seed, energies=e0, n_groups=min(R, 2),
                        n_parts=parts, n_threads=2, replica0=5)
+        assert st["device_decisions"] == (R * n_steps if on_device else 0)
         d_gpu, f_gpu = b.get_trace(n_steps)
         final = {r: b.get_replica(r) for r in check}
     n_rej = n_rot = 0
@@ -1017,3 +1020,42 @@ def test_half_space_k_list_gives_the_reference_structure_factor(orc):
             assert S[j].real == S[i].real and S[j].imag == -S[i].imag
     assert np.abs(half[2] - full[2]).max() < 1e-12 * np.abs(full[2]).max()
     assert np.abs(half[2] - half[5]).max() < 1e-11 * np.abs(half[5]).max()   # running = recomputed
+
+
+@pytest.mark.parametrize("groups,threads,calls", [(2, 2, (41, 23, 1, 2)), (1, 1, (7, 12)), (3, 3, (30, 5))])
+def test_accept_decision_in_the_kernel_gives_the_same_chains(groups, threads, calls):
+    """Option "accept_on_device": the move kernel takes the Metropolis decision itself (the same
+    Philox uniform, dU in the host's arithmetic), keeps accept flag and S-buffer bit in device
+    memory and sends the decision along in its result record; the host only keeps the books.  The
+    chains must be the host-decided ones bit for bit -- energies, counts, coordinates, S(k) --
+    over several calls in a row (odd and even step counts: the record slots alternate; a call of
+    one step), for one and several groups, and a torn result record must still be caught."""
+    a = common.nist_arrays(4, "unwrapped")
+    R = 96
+    res = []
+    for on_device in (0, 1, 1):
+        with make_batch(a, R) as b:
+            b.set_option("kernel", 2)
+            b.set_option("device_moves", 1)
+            b.set_option("persistent", 0)
+            b.set_option("accept_on_device", on_device)
+            if len(res) == 2:
+                b.set_option("inject_torn", 5)
+            e = b.potential_ewald(as_array=True)["energy"].copy()
+            stats, torn = [], []
+            for n in calls:
+                e, st = b.run(n, 298.15, 0.316555789, 0.05, seed=31, energies=e, n_groups=groups,
+                              n_parts=1, n_threads=threads)
+                assert st["device_decisions"] == (n * R if on_device else 0)
+                stats.append([st[q] for q in ("moves", "trans_attempt", "trans_accept", "rot_attempt",
+                                              "rot_accept", "overlaps", "launches")])
+                torn.append(st["torn_records"])
+            assert torn == ([5] + [0] * (len(calls) - 1) if len(res) == 2 else [0] * len(calls))
+            res.append((e.copy(), stats, [b.get_replica(r) for r in (0, R // 2, R - 1)],
+                        b.potential_ewald(as_array=True)["energy"].copy()))
+    for other in res[1:]:
+        assert np.array_equal(res[0][0], other[0]) and res[0][1] == other[1]
+        for x, y in zip(res[0][2], other[2]):
+            assert all(np.array_equal(p, q) for p, q in zip(x, y))
+    assert 0 < sum(c[2] + c[4] for c in res[0][1]) < sum(calls) * R
+    assert np.abs(res[1][0] - res[1][3]).max() < 1e-11 * np.abs(res[1][3]).max()   # running = recomputed
