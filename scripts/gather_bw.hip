@@ -2,10 +2,10 @@
 //
 //   hipcc --offload-arch=gfx950 -O3 -o build/gather_bw scripts/gather_bw.hip && build/gather_bw
 //
-// k_move_eval_wave moves 33.1 KB per trial move: 125 neighbour records gathered as 128-byte lines
-// scattered over the replica's 96 KB record array (16 KB), the replica's S(k) read (5.4 KB) and
-// written to its other buffer (5.4 KB), 4.5 KB of fixed-point centres of mass streamed, a move
-// record in and a result out.  Half of the bytes are 128-byte gathers: a stream copy's 6.29 TB/s
+// k_move_eval_wave moves ~32 KB per trial move: 125 neighbour records gathered as 128-byte lines
+// scattered over the replica's 96 KB record array (16 KB), the replica's S(k) -- the 293 k-vectors a
+// batch keeps of the reference's 337 (k_kvec_setup) -- read (4.7 KB) and written to its other
+// buffer (4.7 KB), 4.5 KB of fixed-point centres of mass streamed, a move record in and a result out.  Half of the bytes are 128-byte gathers: a stream copy's 6.29 TB/s
 // (MI355X_MICROARCH.md) is not the ceiling for that mix.  This program replays the pattern with the
 // same launch shape (1280 workgroups of 4 waves, persistent, one wave per "move", replicas of the
 // same sizes laid out the same way) and reports bytes / time:
@@ -29,7 +29,7 @@
         }                                                                                        \
     } while (0)
 
-constexpr int N_MOL = 750, N_NEIGH = 125, NK = 352;
+constexpr int N_MOL = 750, N_NEIGH = 125, NK = 352 /* stride */, NK_USED = 293;
 constexpr int64_t REC_DOUBLES = 16;                  // 128-byte records
 constexpr int64_t REP_REC = (int64_t)N_MOL * REC_DOUBLES; // doubles of records per replica
 constexpr int64_t REP_S = 2 * 2 * NK;                // two S buffers of NK complex doubles
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, c
                 }
             }
         }
-        if (mode & (4 | 8)) { // S_old read / S_new written: 337 complex doubles, lane per k
-            for (int k = lane; k < 337; k += 64) {
+        if (mode & (4 | 8)) { // S_old read / S_new written: NK_USED complex doubles, lane per k
+            for (int k = lane; k < NK_USED; k += 64) {
                 double2 v = make_double2(1.0, 2.0);
                 if (mode & 4) {
                     if (mode & 128) {
@@ -134,7 +134,7 @@ int main(int argc, char **argv)
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
     struct Case { const char *name; int mode; double bytes_per_unit; };
-    const double gather_b = 125.0 * 128.0, scan_b = 750.0 * 6.0, s_b = 337.0 * 16.0;
+    const double gather_b = 125.0 * 128.0, scan_b = 750.0 * 6.0, s_b = NK_USED * 16.0;
     const Case cases[] = {
         { "gathers only (125 random 128-B lines per unit)", 2, gather_b },
         { "the move kernel's mix: scan + gather + S read + S write", 1 | 2 | 4 | 8, scan_b + gather_b + 2 * s_b },
