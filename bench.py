@@ -225,6 +225,7 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, pers
         b.set_option("wave_wgs", args.wave_wgs)
     b.set_option("zero_copy_moves", shape["zero_copy"])
     b.set_option("device_moves", args.device_moves)
+    b.set_option("accept_on_device", {"auto": -1, "host": 0, "kernel": 1}[args.accept])
     if (args.persistent if persistent is None else persistent) != -1:
         b.set_option("persistent", args.persistent if persistent is None else persistent)
     parts = args.parts if n_parts is None else n_parts
@@ -261,7 +262,7 @@ def measure_moves(R, a, args, local_rank, g0, barrier, shape, n_parts=None, pers
     streams = args.streams if args.streams > 0 else (min(shape["groups"], 2) if args.device_moves else shape["groups"])
     return dict(st=st, elapsed=elapsed, t_full=t_full, drift=drift, energy_sum=float(energies.sum()),
                 launches_per_step=st["launches"] / max(shape["steps"], 1),
-                server=st["server_steps"] > 0, streams=streams)
+                server=st["server_steps"] > 0, streams=streams)  # (st["device_decisions"]: who decided)
 
 
 def launch_mode_roofline(R, a, args, local_rank, g0, barrier, shape, n_mol, box, parts_used):
@@ -605,6 +606,9 @@ def main():
                     help="move server for small batches: -1 = library default (up to one replica per compute unit), "
                          "0 = a launch per step, 1 = insist")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams for the groups (0=auto)")
+    ap.add_argument("--accept", choices=("auto", "host", "kernel"), default="auto",
+                    help="who takes the Metropolis decision (option accept_on_device): auto = the move "
+                         "kernel where a host thread would have more than 4096 records per launch")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
@@ -717,9 +721,12 @@ def main():
                                              f"({pinned[0]}..{pinned[-1]})" if pinned else "inherited affinity"),
                        "prewarm_steps": shape["prewarm"],
                        "move_generation": "device" if args.device_moves else "host",
+                       "accept_decision": "move kernel" if st.get("device_decisions", 0) else "host threads",
+                       "k_vectors": "337 (ewalds.jl:57-89); the batch's kernels work on 293: one of each "
+                                    "exactly-conjugate pair of the kx = 0 plane, twice the weight",
                        **({"short_run_note": f"the timed region of {shape['steps']} steps carries the fill "
                            "and drain of the two-group pipeline (about one kernel time in "
-                           f"{2 * shape['steps']}): a 600-step run of the same command reads ~7 % higher"}
+                           f"{2 * shape['steps']}): a 600-step run of the same command reads ~5 % higher"}
                           if shape["steps"] < 100 else {}),
                        "parallelism": f"replicas x{world}"},
             "acceptance": red["accepted"] / max(total_moves, 1),

@@ -90,6 +90,62 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Six sums over the wave at once, ADDED to out[0..5] by lanes 0..5 (out and scratch: this wave's
+// LDS; scratch 24 doubles).  Bit for bit wave_sum_rows of each -- the same additions in the same
+// order -- for a third of the vector instructions (~55 instead of ~150 per unit of the move kernel):
+//   * the first step packs two sums into one register: even lanes keep a_i + a_(i+1), odd lanes
+//     b_i + b_(i-1) (a quad swap of what the lane does not keep), so the three row_shr steps that
+//     follow -- 2, 4, 8 stay within a parity -- run on three registers instead of six, and lanes 14
+//     and 15 of a row end with the row totals of a and b that lane 15 would have held;
+//   * the four row totals of each sum go through LDS to the lane that adds them, in row order,
+//     instead of through eight v_readlane per sum into every lane.
+__device__ __forceinline__ double dpp_quad_swap_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0xB1, 0xf, 0xf, true),
+                   hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ void wave_sum6_add(double v0, double v1, double v2, double v3, double v4,
+                                              double v5, double *out, double *scratch, int lane)
+{
+    const bool odd = (lane & 1) != 0;
+    double p0 = (odd ? v1 : v0) + dpp_quad_swap_f64(odd ? v0 : v1);
+    double p1 = (odd ? v3 : v2) + dpp_quad_swap_f64(odd ? v2 : v3);
+    double p2 = (odd ? v5 : v4) + dpp_quad_swap_f64(odd ? v4 : v5);
+    p0 += dpp_row_shr_f64<2>(p0); p1 += dpp_row_shr_f64<2>(p1); p2 += dpp_row_shr_f64<2>(p2);
+    p0 += dpp_row_shr_f64<4>(p0); p1 += dpp_row_shr_f64<4>(p1); p2 += dpp_row_shr_f64<4>(p2);
+    p0 += dpp_row_shr_f64<8>(p0); p1 += dpp_row_shr_f64<8>(p1); p2 += dpp_row_shr_f64<8>(p2);
+    if ((lane & 14) == 14) { // lanes 14 and 15 of each row: the row totals of (v0, v1), (v2, v3), (v4, v5)
+        double *dst = scratch + 4 * (lane & 1) + (lane >> 4);
+        dst[0] = p0; dst[8] = p1; dst[16] = p2;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 6) {
+        const double *r = scratch + 4 * lane;
+        out[lane] += ((r[0] + r[1]) + r[2]) + r[3];
+    }
+}
+// (The same packing for the three sums of k_total_wave measured 12 % SLOWER per evaluation, round 4:
+// that kernel is bound by vector issue with its sums in flight beside the next unit's scan.)
+// One sum, the total STORED to *out by lane 0 (scratch: 4 doubles): wave_sum_rows' bits.
+__device__ __forceinline__ void wave_sum1_store(double v, double *out, double *scratch, int lane)
+{
+    v += dpp_row_shr_f64<1>(v);
+    v += dpp_row_shr_f64<2>(v);
+    v += dpp_row_shr_f64<4>(v);
+    v += dpp_row_shr_f64<8>(v);
+    if ((lane & 15) == 15)
+        scratch[lane >> 4] = v;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane == 0)
+        *out = ((scratch[0] + scratch[1]) + scratch[2]) + scratch[3];
+}
+
 __device__ __forceinline__ int lane_i32(int v, int src)
 {
     return __builtin_amdgcn_readlane(v, src);
