@@ -206,7 +206,7 @@ def shape_for(R, args):
     steps = args.steps if args.steps is not None else (3000 if small else 600)
     warmup = args.warmup if args.warmup is not None else (300 if small else 60)
     zero_copy = args.zero_copy_moves if args.zero_copy_moves >= 0 else (1 if small else 0)
-    prewarm = max(0, (120 if not small else 600) - warmup)
+    prewarm = max(0, (int(os.environ.get("MMC_BENCH_PREWARM", "120")) if not small else 600) - warmup)
     return dict(groups=groups, threads=max(threads, 1), steps=steps, warmup=warmup,
                 zero_copy=zero_copy, prewarm=prewarm)
 
