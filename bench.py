@@ -16,7 +16,8 @@ HBM before the timed region; the trial moves are drawn on the device (k_propose,
 so per step one flag byte per replica travels to the device and 64 B of results come back
 (--device-moves 0: the host draws the moves and sends 232 B per replica and step).
 
-The default R = 65536 fills the device (the headline line).  BASELINE's two named replica counts
+The default R = 61440 fills the device (the headline line): two groups of 30720 = six replicas for
+each of the 5120 wavefronts the move kernel keeps resident, so that the waves of a launch end together.  BASELINE's two named replica counts
 are first-class too: `--replicas 1` (configs[1]) and `--replicas 32` (configs[2]'s share of one
 GPU) print the same contract line with their own roofline object; the default run also carries
 both as `named_configs`.
@@ -103,20 +104,26 @@ def pmc_traffic(kernel, moves_per_launch):
                                    "command (committed); not measured in this run")
 
 
-def access_pattern_peak():
-    """(GB/s, microseconds per 32768-move launch, source) of scripts/gather_bw.hip: the move kernel's
-    memory access pattern -- COM-code stream, 125 scattered 128-byte record lines, S(k) read and
-    written, per unit, same launch shape -- replayed WITHOUT its arithmetic (committed under
-    profiles/; not measured in this run)."""
+def access_pattern_floor(units_per_launch, steps_per_launch):
+    """(microseconds per launch, TB/s of the pattern's bytes, source) of scripts/gather_bw.hip: the move
+    kernel's memory accesses -- per unit and step the COM-code stream, 125 scattered 128-byte record
+    lines, S(k) read and written; same launch shape, the same number of consecutive steps per unit by
+    the same wave -- replayed WITHOUT its arithmetic (committed under profiles/; not measured in
+    this run).  None unless the replay was made for this launch shape."""
     try:
         path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles"))
                       if p.endswith("_access_pattern_bw.json"))[-1]
         t = json.load(open(os.path.join(ROOT, "profiles", path)))
-        c = next(c for c in t["cases"] if c["pattern"].startswith("the move kernel's mix"))
-        if int(t["units_per_launch"]) != 32768:
+        if int(t["units_per_launch"]) != int(units_per_launch):
             return None
-        return 1e3 * c["TB_per_s"], c["us_per_launch"], (f"profiles/{path}: scripts/gather_bw.hip, the kernel's loads and "
-                                                        "stores without its arithmetic (committed; not measured in this run)")
+        if int(steps_per_launch) <= 1:
+            c = next(c for c in t["cases"] if c["pattern"].startswith("the move kernel's mix"))
+            us, tbs = c["us_per_launch"], c["TB_per_s"]
+        else:
+            c = next(c for c in t["steps_per_unit"] if int(c["K"]) == int(steps_per_launch))
+            us, tbs = c["us_per_unit_steps_of_one_launch"] * steps_per_launch, c["TB_per_s_of_the_pattern_bytes"]
+        return us, tbs, (f"profiles/{path}: scripts/gather_bw.hip, the kernel's loads and stores without its "
+                         "arithmetic, same units and steps per launch (committed; not measured in this run)")
     except (IndexError, OSError, ValueError, KeyError, StopIteration):
         return None
 
@@ -204,7 +211,7 @@ def shape_for(R, args):
     if small: # the move server steps every replica at its own pace: a thread per ~8 replicas
         threads = max(1, min(threads, R // 8))
     steps = args.steps if args.steps is not None else (3000 if small else 600)
-    warmup = args.warmup if args.warmup is not None else (300 if small else 60)
+    warmup = args.warmup if args.warmup is not None else (300 if small else 64)  # (multiples of the 8 steps a launch takes)
     zero_copy = args.zero_copy_moves if args.zero_copy_moves >= 0 else (1 if small else 0)
     prewarm = max(0, (int(os.environ.get("MMC_BENCH_PREWARM", "120")) if not small else 600) - warmup)
     return dict(groups=groups, threads=max(threads, 1), steps=steps, warmup=warmup,
@@ -310,6 +317,7 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         return None
     bytes_move = algorithmic_bytes_per_move(n_mol, box)
     moves_per_launch = st["moves"] / max(st["launches"], 1)
+    steps_per_launch = max(1, int(round(moves_per_launch * shape["groups"] / max(R, 1))))
     overlapped = res.get("streams", 1) > 1 and shape["groups"] > 1
     span = (st["kernel_ms"] * 1e-3 / st["timed_launches"]) if st["timed_launches"] else None
     if overlapped or span is None:
@@ -337,6 +345,7 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         "launches": int(st["launches"]),
         "launches_timed_with_events": int(st["timed_launches"]),
         "algorithmic_bytes_per_move": bytes_move, "moves_per_launch": moves_per_launch,
+        "steps_per_launch": steps_per_launch,
         "launches_per_move": st["launches"] / max(st["moves"], 1),
         "frac_of_measured_copy_peak_6290": achieved / 6290.0,
     }
@@ -353,15 +362,20 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
             b["hbm"] = {"achieved": hb, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hb / HBM_PEAK_GBS,
                         "bytes_per_move": traffic / moves_per_launch,
                         "frac_of_measured_copy_peak_6290": hb / 6290.0}
-            pat = access_pattern_peak()
-            if pat:   # what HBM delivers for THIS kernel's access pattern with no arithmetic at all
-                b["hbm"].update(pattern_peak=pat[0], frac_of_pattern_peak=hb / pat[0], pattern_floor_us=pat[1],
-                                pattern_source=pat[2])
-                if hb / pat[0] > valu["frac"]:   # the larger fraction names the bound
-                    b.update(bound="hbm_access_pattern", achieved=hb, peak=pat[0], unit="GB/s", frac=hb / pat[0],
-                             peak_is="counter bytes of the kernel against what its own loads and stores reach "
-                                     "with the arithmetic removed (scripts/gather_bw.hip: code stream, scattered "
-                                     "128-byte record lines, S(k) read and written; same launch shape)")
+        # what the kernel's own loads and stores take with the arithmetic removed: the time of that
+        # replay over the time of the launch (<= 1: how close the kernel is to being nothing but its
+        # memory accesses)
+        pat = access_pattern_floor(moves_per_launch / max(steps_per_launch, 1), steps_per_launch)
+        if pat:
+            pf = pat[0] * 1e-6 / t_launch
+            b["access_pattern"] = {"floor_us": pat[0], "frac": pf, "TB_per_s_of_its_bytes_without_arithmetic": pat[1],
+                                   "source": pat[2]}
+            if pf > valu["frac"]:   # the larger fraction names the bound
+                b.update(bound="hbm_access_pattern", achieved=1e6 * t_launch, peak=pat[0], unit="us per launch (floor / achieved)",
+                         frac=pf, peak_is="the time the kernel's own loads and stores take with the arithmetic "
+                                          "removed (scripts/gather_bw.hip: code stream, scattered 128-byte record "
+                                          "lines, S(k) read and written; same launch shape and steps per launch) "
+                                          "over the time of the launch")
         for k in ("lds_busy_frac", "lds_conflict_frac", "wait_frac", "salu_insts_per_move", "waves_per_simd"):
             if k in ex:
                 b[k] = ex[k]
@@ -586,8 +600,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default 600 (3000 below 4096 replicas)")
-    ap.add_argument("--warmup", type=int, default=None, help="default 60 (300 below 4096 replicas)")
-    ap.add_argument("--replicas", type=int, default=65536, help="replicas per GPU")
+    ap.add_argument("--warmup", type=int, default=None, help="default 64 (300 below 4096 replicas)")
+    ap.add_argument("--replicas", type=int, default=61440,
+                    help="replicas per GPU (default: 2 groups x 6 x the 5120 wavefronts the move kernel keeps resident)")
     ap.add_argument("--groups", type=int, default=0,
                     help="replica groups pipelined per GPU (0 = 2, or 1 for a single chain)")
     ap.add_argument("--parts", type=int, default=0, help="units per replica-move (0=auto)")
@@ -799,8 +814,8 @@ def main():
                 # Same pre-warm as the headline (a cold side run was what made round 3's
                 # `two_streams` line read 6.7e7 in the driver's run).
                 a1 = argparse.Namespace(**{**vars(args), "streams": 1})
-                sh1 = dict(shape, steps=min(max(shape["steps"], 100), 200), warmup=min(shape["warmup"], 20),
-                           prewarm=100)
+                sh1 = dict(shape, steps=min(max(shape["steps"], 100), 200), warmup=min(shape["warmup"], 24),
+                           prewarm=104)
                 r_ = measure_moves(R, a, a1, local_rank, g0, barrier, sh1)
                 rf1 = roofline_object(r_, R, a1, sh1, n_mol, box, parts_used)
                 out["one_stream"] = {

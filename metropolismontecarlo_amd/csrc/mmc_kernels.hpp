@@ -446,12 +446,24 @@ __host__ __device__ inline double mmc_move_delta(const double *w7, bool ov_old, 
 // on the host, without the trip there and back between two steps of a chain.  The kernel rewrites
 // the replica's flag byte (accept | S-buffer << 1) for the NEXT launch's commit and sends the
 // decision to the host in its result record, which the host uses for its bookkeeping as it is.
+struct MoveRec;
 struct DecideConsts {
     double temperature, factor;
     uint64_t seed;
-    uint32_t replica0, _pad;
+    uint32_t replica0;
+    int32_t ring_slots;     // several steps per launch: the ring of device-made move records,
+    const MoveRec *ring;    // [ring_slots][ring_stride], by step % ring_slots
+    int64_t ring_stride;
     uint8_t *flags; // [R]
 };
+// Several steps of a chain in ONE launch (the same wave takes the replica through them: what it
+// wrote and read in one step is in the caches for the next): the launch sends ONE record per
+// replica, a PartOut whose words are
+//   [0] the sum of dU over the accepted steps, added up in step order
+//   [1] bit k: step k accepted; bit 16 + k: step k saw an overlap; bit 32 + k: step k was a rotation
+//       (an integer in a double's bits)
+//   [2..6] 0;  word 7 as ever (stamp, checksum; bit 31: the LAST step's decision)
+#define MMC_STEPS_PER_LAUNCH_MAX 16
 
 // grid (n_parts, R).  n_parts == 1: the workgroup scans all molecules and then does the
 // reciprocal part.  n_parts > 1: parts 0..n_parts-2 split the molecule range, the last part does

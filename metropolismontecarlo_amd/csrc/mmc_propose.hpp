@@ -276,6 +276,7 @@ __global__ void k_propose(BatchView bv, const double *rec, MoveRec *ring, GenArg
         for (int q = 0; q < 4; q++) q_old[q] = qsrc[q];
         const Uniform2 u0 = mmc_draw(ck, rs, MMC_SLOT_KIND);
         const Uniform2 u1 = mmc_draw(ck, rs, MMC_SLOT_MOVE);
+        m.flags = u0.a < 0.5 ? 0 : 256; // (bit 8: the kind of the move, for a kernel that keeps the counts)
         if (u0.a < 0.5) { // translation: random_translate_vector + PBC, ei = quat[i] (:519-528)
             const double zeta[3] = { u0.b - 0.5, u1.a - 0.5, u1.b - 0.5 };
             for (int k = 0; k < 3; k++) m.com_new[k] = pbc_wrap(com[k] + zeta[k] * sz.x, bv.box);
@@ -303,6 +304,7 @@ __global__ void k_propose(BatchView bv, const double *rec, MoveRec *ring, GenArg
         for (int q = 0; q < 4; q++) m.q_new[q] = q_new[q];
     } else {
         const MoveXform x = propose_xform(ck, rs, bv.box, sz.x, sz.y, com);
+        m.flags = x.kind << 8;
         for (int q = 0; q < 3; q++) m.com_new[q] = x.com_new[q];
         for (int a = 0; a < 3; a++)
             apply_xform(x, com, &at[3 * a], &m.atoms_new[3 * a]);

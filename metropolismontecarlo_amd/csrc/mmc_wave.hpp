@@ -193,9 +193,11 @@ __device__ __forceinline__ void phase_row_moderate(double x, double L, cplx *row
 // the unit's seven sums in LDS; lane 0 rewrites the replica's flag byte.  Returns accept (0 / 1).
 __device__ __forceinline__ int wave_decide(const double *outw, bool ov_old, bool ov_new,
                                            const DecideConsts *__restrict__ dc, long long step, int r,
-                                           int scur, int lane)
+                                           int scur, int lane, double *delta_out = nullptr, bool store_flags = true)
 {
     const double delta = mmc_move_delta(outw, ov_old, ov_new, dc->factor);
+    if (delta_out)
+        *delta_out = delta;
     const double x = delta / dc->temperature;
     const double u = mmc_metropolis_uniform(ChainKey{ dc->seed, dc->replica0 + (uint32_t)r }, (uint64_t)step);
     // exp(-x) > u, decided without the exponential where 1 - x <= exp(-x) <= 1 / (1 + x) (x >= 0)
@@ -208,7 +210,7 @@ __device__ __forceinline__ int wave_decide(const double *outw, bool ov_old, bool
     else if ((1.0 + x) * u > 1.0 + 1e-9) met = false;
     else met = exp(-x) > u;
     const int acc = (met && !(ov_old || ov_new)) ? 1 : 0;
-    if (lane == 0)
+    if (store_flags && lane == 0)
         dc->flags[r] = (uint8_t)(acc | ((scur ^ acc) << 1));
     return acc;
 }
@@ -222,13 +224,17 @@ __device__ __forceinline__ int wave_decide(const double *outw, bool ov_old, bool
 // unit, same L1) instead of substituting the pending words in every gather and scan block.
 // IMG = true: the minimum image of an atom pair from the image of its molecule (WV_IMG in
 // mmc_wave_unit.inc; the launch site checks the condition).
-template <bool SUBST, bool IMG>
+// MULTI = true: several steps of the chain per launch (n_sub; the kernel decides) -- its own
+// instantiation, so that the one-step form compiles exactly as it did.
+template <bool SUBST, bool IMG, bool MULTI = false>
 __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(WV_OCC, WV_OCC))) void k_move_eval_wave(
     BatchView bv, double *rec, const double *__restrict__ qq_tab,
     const int32_t *__restrict__ kpack, FastConsts fc, const MoveRec *__restrict__ cur,
     const MoveRec *__restrict__ prev, PartOut *out, int n_parts, PairParams pp, int r_base,
-    int n_units, const uint8_t *flagv, unsigned stamp, const DecideConsts *__restrict__ dc, long long dec_step)
+    int n_units, const uint8_t *flagv, unsigned stamp, const DecideConsts *__restrict__ dc, long long dec_step,
+    int n_sub_arg, int slot0)
 {
+    const int n_sub = MULTI ? n_sub_arg : 1;
     __shared__ __align__(16) WaveSharedT<WV_MWAVES> sm;
     const int tid = threadIdx.x, lane0 = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
         // to scratch and reloaded once per unit, long before its use.  Computing the lane id
         // anew per unit in asm instead -- no range information for the compiler -- ran 4 % slower.)
         int lane = lane0;
-        asm volatile("" : "+v"(lane));
+        if (!MULTI)
+            asm volatile("" : "+v"(lane));
         int rl = unit, part = 0;
         if (n_parts != 1) {
             rl = unit / n_parts;
@@ -272,25 +279,45 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
         const int j_end = do_pairs ? min(j_begin + plen, n_mol) : 0;
         double *const myrec = rec + (int64_t)r * n_mol * MMC_RSTRIDE;
 
+        // n_sub > 1 (the kernel decides, one part per move): this wave takes the replica through n_sub
+        // consecutive steps -- commit, evaluate, decide, and again -- and sends one record for all
+        // of them (DecideConsts).  What a step wrote and read is in the L2 / the Infinity Cache for
+        // the next: the same memory accesses without the arithmetic take 0.72 of the time at four
+        // steps per launch (scripts/gather_bw.hip).  Carried from step to step in scalars:
+        int flags_carry = -1;            // accept | S-buffer bit << 1 after the step before
+        double e_sum = 0.0;              // dU of the accepted steps, in step order
+        unsigned acc_mask = 0, ovl_mask = 0, kind_mask = 0;
+      for (int sub = 0; sub < n_sub; sub++) {
+        if (MULTI) { // (opaque once per STEP here: see above; the steps are a loop inside the unit's)
+            lane = lane0;
+            asm volatile("" : "+v"(lane));
+        }
+        const MoveRec *cur_s = cur, *prev_s = prev;
+        if (n_sub > 1) {
+            const int sl = (slot0 + sub) % dc->ring_slots, slp = (slot0 + sub + dc->ring_slots - 1) % dc->ring_slots;
+            cur_s = dc->ring + (int64_t)sl * dc->ring_stride;
+            if (sub > 0)
+                prev_s = dc->ring + (int64_t)slp * dc->ring_stride;
+        }
         WV_STAMP(0); // unit start
         // ---- the move record: one load instruction (lane t holds word t), then scalars ----
-        const double *mvp = reinterpret_cast<const double *>(cur + r);
+        const double *mvp = reinterpret_cast<const double *>(cur_s + r);
         double w = 0.0;
         if (lane < MV_Q_NEW)
             w = mvp[lane];
         WV_STAMP(1); // move record arrived
-        const int gflag = flagv ? __builtin_amdgcn_readfirstlane((int)flagv[r]) : -1;
+        const int gflag = flags_carry >= 0 ? flags_carry : (flagv ? __builtin_amdgcn_readfirstlane((int)flagv[r]) : -1);
         const long long hdr = __double_as_longlong(w);
         const int i0 = lane_i32((int)hdr, 0) - 1;
         const int flags = gflag >= 0 ? gflag : lane_i32((int)(hdr >> 32), 0);
-        const bool commit = prev && (flags & 1);
+        const bool commit = prev_s && (flags & 1);
         const int scur = (flags >> 1) & 1;
 
         // pending commit of the previous accepted move (main.jl:598-621): written by part 0;
         // every reader of this launch substitutes the pending words for that molecule
         int pend = -1;
         if (commit) {
-            const double *pvp = reinterpret_cast<const double *>(prev + r);
+            const double *pvp = reinterpret_cast<const double *>(prev_s + r);
             double pw = 0.0;
             if (lane < 9) pw = pvp[MV_AT_NEW + lane];
             else if (lane < 12) pw = pvp[MV_COM_NEW + lane - 9];
@@ -322,7 +349,36 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
         // (expanded where they are used: as variables they would be live across the whole unit)
 #define WV_CQ_BASE (bv.comq + (int64_t)r * 3 * bv.cq_stride)
 #define WV_PART_DST (out + (int64_t)r * n_parts + part)
-#define WV_DECIDE(o0, o1) (dc ? wave_decide(outw, o0, o1, dc, dec_step, r, scur, lane) : 0)
+        // the decision, and with several steps per launch the bookkeeping between them: the last
+        // step replaces the seven sums in outw by the launch's record (mmc_kernels.hpp)
+        auto decide_here = [&](bool o0, bool o1) -> int {
+            if (!dc)
+                return 0;
+            if (n_sub <= 1)
+                return wave_decide(sm.outw[wv], o0, o1, dc, dec_step, r, scur, lane);
+            double delta;
+            const bool last = sub + 1 == n_sub;
+            const int acc = wave_decide(sm.outw[wv], o0, o1, dc, dec_step + sub, r, scur, lane, &delta, last);
+            if (acc) {
+                e_sum += delta;
+                acc_mask |= 1u << sub;
+            }
+            if (o0 || o1)
+                ovl_mask |= 1u << sub;
+            kind_mask |= (unsigned)((lane_i32((int)(hdr >> 32), 0) >> 8) & 1) << sub; // (k_propose's note in the record)
+            flags_carry = acc | ((scur ^ acc) << 1);
+            if (last) {
+                wave_sync();
+                if (lane < 7)
+                    sm.outw[wv][lane] = lane == 0 ? e_sum
+                                 : lane == 1 ? __longlong_as_double((long long)(acc_mask | (ovl_mask << 16)) | ((long long)kind_mask << 32)) : 0.0;
+                wave_sync();
+            }
+            return acc;
+        };
+#define WV_DECIDE(o0, o1) decide_here(o0, o1)
+#define WV_RECORD_OVL(o) (n_sub > 1 ? false : (o))
+#define WV_STORE_IF (sub + 1 == n_sub)
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
 #define WV_IMG IMG
@@ -346,6 +402,11 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #undef WV_CQ_BASE
 #undef WV_PART_DST
 #undef WV_DECIDE
+#undef WV_RECORD_OVL
+#undef WV_STORE_IF
+        if (n_sub > 1) // what this step stored (S_new, soon the commit) is read by the next
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } // sub
     }
 }
 

@@ -116,6 +116,49 @@ __global__ __launch_bounds__(256) void k_pattern(const double *rec, double *S, c
         sink[0] = acc;
 }
 
+// The same mix with K consecutive "steps" per unit by the same wave (what a kernel that took the
+// accept decision itself could do): step k reads the S buffer step k-1 wrote, the same codes, and 125
+// lines of the same 96 KB of records (another random draw: two molecules' neighbour sets share ~17 %).
+// How much of that is then served by the L2 / the 256 MiB Infinity Cache instead of HBM?
+template <int K>
+__global__ __launch_bounds__(256) void k_pattern_steps(const double *rec, double *S, const uint16_t *cq,
+                                                       int n_units, unsigned salt, double *sink)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int unit = blockIdx.x * 4 + wv; unit < n_units; unit += gridDim.x * 4) {
+        const double *myrec = rec + (int64_t)unit * REP_REC;
+        double *myS = S + (int64_t)unit * REP_S;
+        for (int step = 0; step < K; step++) {
+            const uint32_t *xy = reinterpret_cast<const uint32_t *>(cq + (int64_t)unit * REP_CQ);
+            const uint16_t *z = cq + (int64_t)unit * REP_CQ + 2 * 768;
+#pragma unroll
+            for (int b = 0; b < 12; b++)
+                acc += (double)(xy[64 * b + lane] ^ z[64 * b + lane]);
+            for (int round = 0; round < 2; round++) {
+                const int n = 64 * round + lane;
+                int j = (int)(hash32((unsigned)unit * 131u + (unsigned)n + salt + 7919u * step) % N_MOL);
+                if (n >= N_NEIGH)
+                    j = 0;
+                const double2 *src = reinterpret_cast<const double2 *>(myrec + (int64_t)j * REC_DOUBLES);
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+                    const double2 v = src[q];
+                    acc += v.x + v.y;
+                }
+            }
+            const int cur = step & 1;
+            for (int k = lane; k < NK_USED; k += 64) {
+                double2 v = *reinterpret_cast<const double2 *>(myS + 2 * NK * cur + 2 * k);
+                *reinterpret_cast<double2 *>(myS + 2 * NK * (cur ^ 1) + 2 * k) = make_double2(v.x + 1.0, v.y);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    if (acc == 1.2345e300)
+        sink[0] = acc;
+}
+
 int main(int argc, char **argv)
 {
     const int n_units = argc > 1 ? atoi(argv[1]) : 32768;
@@ -178,6 +221,29 @@ int main(int argc, char **argv)
         printf("%s{\"pattern\": \"%s\", \"bytes_per_unit\": %.0f, \"us_per_launch\": %.1f, \"TB_per_s\": %.3f}",
                first ? "" : ", ", c.name, c.bytes_per_unit, us, tbs);
         first = false;
+    }
+    printf("], \"steps_per_unit\": [");
+    {   // K steps per unit by the same wave: time per unit-STEP
+        const double bytes = scan_b + gather_b + 2 * s_b;
+        auto run = [&](int K, auto kern) {
+            for (int w = 0; w < 2; w++)
+                kern(w & 1, 17u * w);
+            CHECK(hipDeviceSynchronize());
+            const int rr = reps / K > 4 ? reps / K : 4;
+            CHECK(hipEventRecord(e0));
+            for (int i = 0; i < rr; i++)
+                kern(i & 1, 1000u + 31u * i);
+            CHECK(hipEventRecord(e1));
+            CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / rr / K;
+            printf("%s{\"K\": %d, \"us_per_unit_steps_of_one_launch\": %.1f, \"TB_per_s_of_the_pattern_bytes\": %.3f}", K == 1 ? "" : ", ", K, us,
+                   bytes * n_units / (us * 1e-6) / 1e12);
+        };
+#define STEPS_CASE(KK) run(KK, [&](int grp, unsigned salt) { k_pattern_steps<KK><<<1280, 256>>>(rec + (int64_t)grp * REP_REC * n_units, S + (int64_t)grp * REP_S * n_units, cq + (int64_t)grp * REP_CQ * n_units, n_units, salt, sink); });
+        STEPS_CASE(1) STEPS_CASE(2) STEPS_CASE(4) STEPS_CASE(8) STEPS_CASE(16)
+#undef STEPS_CASE
     }
     printf("]}\n");
     return 0;

@@ -43,6 +43,12 @@ def test_launch_duration_is_cost_when_launches_overlap():
                                               / (r["avg_launch_us"] * 1e-6) / 1e9)
 
 
+def test_steps_per_launch_is_read_from_the_counts():
+    st = {"launches": 10, "moves": 30720 * 8 * 10, "timed_launches": 0, "kernel_ms": 0.0}
+    r = bench.roofline_object({"st": st, "elapsed": 0.017, "streams": 2}, 61440, ARGS, {"groups": 2}, 750, 30.0, 1)
+    assert r["steps_per_launch"] == 8 and r["moves_per_launch"] == 30720 * 8
+
+
 def test_binding_block_names_the_larger_fraction_and_stays_below_one():
     r = bench.roofline_object(fake(2), 65536, ARGS, {"groups": 2}, 750, 30.0, 1)
     b = r.get("binding")
@@ -53,9 +59,10 @@ def test_binding_block_names_the_larger_fraction_and_stays_below_one():
     assert v["achieved"] == pytest.approx(v["valu_insts_per_move"] * 32768 / (r["avg_launch_us"] * 1e-6) / 1e9)
     assert 0 < v["frac"] <= 1.0 and 0 < h["frac"] <= 1.0
     cands = {"fp64_valu_issue": v["frac"]}
-    if "frac_of_pattern_peak" in h:
-        assert 0 < h["frac_of_pattern_peak"] <= 1.0
-        cands["hbm_access_pattern"] = h["frac_of_pattern_peak"]
+    if "access_pattern" in b:   # the kernel's loads and stores without arithmetic: their time / the launch's
+        assert 0 < b["access_pattern"]["frac"] <= 1.0
+        assert b["access_pattern"]["frac"] == pytest.approx(b["access_pattern"]["floor_us"] / r["avg_launch_us"])
+        cands["hbm_access_pattern"] = b["access_pattern"]["frac"]
     assert b["bound"] == max(cands, key=cands.get) and b["frac"] == pytest.approx(max(cands.values()))
     assert "not measured in this run" in b["counters_source"]
 
@@ -63,7 +70,7 @@ def test_binding_block_names_the_larger_fraction_and_stays_below_one():
 def test_shapes():
     a = argparse.Namespace(groups=0, threads=8, steps=None, warmup=None, zero_copy_moves=-1)
     big, small = bench.shape_for(65536, a), bench.shape_for(32, a)
-    assert big["groups"] == 2 and big["steps"] == 600 and big["prewarm"] == 60
+    assert big["groups"] == 2 and big["steps"] == 600 and big["warmup"] == 64 and big["prewarm"] == 56
     assert small["threads"] == 4 and small["steps"] == 3000 and bench.shape_for(1, a)["groups"] == 1
     assert bench.default_parts(65536, 750) == 1 and bench.default_parts(32, 750) == 5
     assert bench.server_lat_parts(1, 750) == 16 and bench.server_lat_parts(1, 10000) == 84

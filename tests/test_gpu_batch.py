@@ -621,7 +621,10 @@ def test_bench_path_750_molecules_device_moves(kernel, orc):
         e0 = b.potential_ewald(as_array=True)["energy"].copy()
         e1, st = b.run(n_steps, 298.15, 0.316555789, 0.05, seed=11234, energies=e0, n_groups=2,
                        n_parts=1, n_threads=2)
-        assert st["moves"] == n_steps * R and st["launches"] == 2 * n_steps
+        # (where the wave kernel takes the decisions itself it takes eight steps per launch; 64 chains
+        # run on the move server, which counts a launch per step and group)
+        assert st["moves"] == n_steps * R
+        assert st["launches"] == 2 * (-(-n_steps // 8) if st["device_decisions"] else n_steps)
         assert st["torn_records"] == 0
         acc = (st["trans_accept"] + st["rot_accept"]) / st["moves"]
         assert 0.6 < acc < 0.9, acc                 # 0.756 in the bench's runs
@@ -969,7 +972,7 @@ def test_stream_layout_does_not_change_the_chains(groups, threads):
         assert np.array_equal(res[0][0], other[0]) and res[0][1] == other[1]
         for x, y in zip(res[0][2], other[2]):
             assert all(np.array_equal(p, q) for p, q in zip(x, y))
-    assert res[0][1][0][0] == 41 * R and res[0][1][0][4] == 41 * groups
+    assert res[0][1][0][0] == 41 * R and res[0][1][0][4] == -(-41 // 8) * groups   # eight steps per launch
 
 
 def test_half_space_k_list_gives_the_reference_structure_factor(orc):
@@ -1022,40 +1025,52 @@ def test_half_space_k_list_gives_the_reference_structure_factor(orc):
     assert np.abs(half[2] - half[5]).max() < 1e-11 * np.abs(half[5]).max()   # running = recomputed
 
 
-@pytest.mark.parametrize("groups,threads,calls", [(2, 2, (41, 23, 1, 2)), (1, 1, (7, 12)), (3, 3, (30, 5))])
+@pytest.mark.parametrize("groups,threads,calls", [(2, 2, (41, 23, 1, 2)), (1, 1, (7, 12)), (3, 3, (30, 5, 17))])
 def test_accept_decision_in_the_kernel_gives_the_same_chains(groups, threads, calls):
     """Option "accept_on_device": the move kernel takes the Metropolis decision itself (the same
     Philox uniform, dU in the host's arithmetic), keeps accept flag and S-buffer bit in device
-    memory and sends the decision along in its result record; the host only keeps the books.  The
-    chains must be the host-decided ones bit for bit -- energies, counts, coordinates, S(k) --
-    over several calls in a row (odd and even step counts: the record slots alternate; a call of
-    one step), for one and several groups, and a torn result record must still be caught."""
+    memory and sends the decision along in its result record; the host only keeps the books.  With
+    "steps_per_launch" > 1 the same wave takes a replica through several steps per launch and sends
+    one record for all of them.  The chains must be the host-decided ones bit for bit -- counts,
+    coordinates, S(k); the energies too with one step per launch, and to the order of a sum with
+    several -- over several calls in a row (step counts that are and are not multiples of the steps
+    per launch; a call of one step), for one and several groups, and a torn result record must still
+    be caught."""
     a = common.nist_arrays(4, "unwrapped")
     R = 96
     res = []
-    for on_device in (0, 1, 1):
+    modes = [(0, 1, 0), (1, 1, 0), (1, 1, 5), (1, 2, 0), (1, 8, 0), (1, 16, 3), (-1, 0, 0)]
+    for on_device, per_launch, torn_in in modes:
         with make_batch(a, R) as b:
             b.set_option("kernel", 2)
             b.set_option("device_moves", 1)
             b.set_option("persistent", 0)
             b.set_option("accept_on_device", on_device)
-            if len(res) == 2:
-                b.set_option("inject_torn", 5)
+            b.set_option("steps_per_launch", per_launch)
+            if torn_in:
+                b.set_option("inject_torn", torn_in)
             e = b.potential_ewald(as_array=True)["energy"].copy()
-            stats, torn = [], []
+            stats, torn, launches = [], [], []
             for n in calls:
                 e, st = b.run(n, 298.15, 0.316555789, 0.05, seed=31, energies=e, n_groups=groups,
                               n_parts=1, n_threads=threads)
                 assert st["device_decisions"] == (n * R if on_device else 0)
                 stats.append([st[q] for q in ("moves", "trans_attempt", "trans_accept", "rot_attempt",
-                                              "rot_accept", "overlaps", "launches")])
+                                              "rot_accept", "overlaps")])
+                launches.append(st["launches"])
                 torn.append(st["torn_records"])
-            assert torn == ([5] + [0] * (len(calls) - 1) if len(res) == 2 else [0] * len(calls))
+            assert torn == [torn_in] + [0] * (len(calls) - 1)
+            k = per_launch if per_launch else 8                 # (0: by size -- eight here)
+            assert launches == [-(-n // k) * groups for n in calls]
             res.append((e.copy(), stats, [b.get_replica(r) for r in (0, R // 2, R - 1)],
                         b.potential_ewald(as_array=True)["energy"].copy()))
-    for other in res[1:]:
-        assert np.array_equal(res[0][0], other[0]) and res[0][1] == other[1]
+    for (on_device, per_launch, _), other in zip(modes[1:], res[1:]):
+        assert res[0][1] == other[1]
+        if per_launch == 1:
+            assert np.array_equal(res[0][0], other[0])
+        assert np.abs(res[0][0] - other[0]).max() < 1e-12 * np.abs(res[0][0]).max()
         for x, y in zip(res[0][2], other[2]):
             assert all(np.array_equal(p, q) for p, q in zip(x, y))
     assert 0 < sum(c[2] + c[4] for c in res[0][1]) < sum(calls) * R
-    assert np.abs(res[1][0] - res[1][3]).max() < 1e-11 * np.abs(res[1][3]).max()   # running = recomputed
+    for q in res:
+        assert np.abs(q[0] - q[3]).max() < 1e-11 * np.abs(q[3]).max()   # running = recomputed
