@@ -9,12 +9,15 @@ Ewald/coord750.txt, shipped as metropolismontecarlo_amd/data/spce_nist.npz), NVT
 (kappa = 5.6/L, 337 k-vectors), fp64, r_cut = 10 A.  R independent replicas per GPU (one Markov
 chain each; chain r of rank k draws from the stream (seed, k*R + r)); replicas shard across ranks
 with no data-path collective (weak scaling: R per GPU is fixed).  A *step* is one trial move of
-every replica of the rank: one fused launch of the move kernel (2x LJ_poly_dU + 2x EwaldShort +
-RecipMove + commit of the previous accepted move) per replica group, followed by the sequential
-Metropolis accept/reject on the host (native C++ driver, mmc_batch_run).  Inputs are resident in
-HBM before the timed region; the trial moves are drawn on the device (k_propose, Philox4x32-10),
-so per step one flag byte per replica travels to the device and 64 B of results come back
-(--device-moves 0: the host draws the moves and sends 232 B per replica and step).
+every replica of the rank: the fused move kernel (2x LJ_poly_dU + 2x EwaldShort + RecipMove +
+commit of the previous accepted move) and the sequential Metropolis accept/reject of
+Loop() (main.jl:593-651) for every replica.  By default the kernel takes the decision itself (same
+Philox uniform, same arithmetic: the chains are the host-decided ones bit for bit) and one launch
+per replica group takes every replica through eight consecutive steps, sending one result record
+per replica and launch to the host, which keeps the books (native C++ driver, mmc_batch_run);
+`--accept host` leaves the decision to the host's threads, one launch and 64 B per step.  Inputs are
+resident in HBM before the timed region; the trial moves are drawn on the device (k_propose,
+Philox4x32-10; --device-moves 0: the host draws the moves and sends 232 B per replica and step).
 
 The default R = 61440 fills the device (the headline line): two groups of 30720 = six replicas for
 each of the 5120 wavefronts the move kernel keeps resident, so that the waves of a launch end together.  BASELINE's two named replica counts
@@ -760,8 +763,11 @@ def main():
             "algorithmic_flops": flops_full, "algorithmic_bytes": algorithmic_bytes_full_eval(n_mol),
             "achieved_tflops_per_gpu": flops_full * R / t_full_max / 1e12,
             "frac_fp64_vector_peak_78.6": flops_full * R / t_full_max / 1e12 / FP64_PEAK_TFLOPS}
+        spl = max(1, int(round(shape["groups"] * st["moves"] / max(st["launches"], 1) / max(R, 1))))
         out["config"]["driver"] = ("persistent move server (one kernel per run)" if res["server"]
-                                   else "one launch per step and group")
+                                   else "one launch per step and group" if spl == 1
+                                   else f"one launch per {spl} steps and group: the wave that decides takes a replica "
+                                        "through them, one result record per replica and launch")
         rf = (launch_mode_roofline(R, a, args, local_rank, g0, lambda: torch.cuda.synchronize(),
                                    shape, n_mol, box, parts_used) if res["server"]
               else roofline_object(res, R, args, shape, n_mol, box, parts_used))
@@ -777,7 +783,8 @@ def main():
             "lj_pair_terms_per_s": v * 2 * mbar, "phase_terms_per_s": v * N_K * 6,
             "move_kernel_launches_per_move": st["launches"] / max(st["moves"], 1),
             "stream_syncs_per_move": 0.0,
-            "pcie_bytes_per_move": {"h2d": 1 if args.device_moves else 232, "d2h": 64 * parts_used}}
+            "pcie_bytes_per_move": {"h2d": (0 if st.get("device_decisions") else 1) if args.device_moves else 232,
+                                    "d2h": 64 * parts_used / spl}}
         if not args.no_secondary and world == 1:   # side measurements: single-GPU runs only
             # BASELINE's two named replica counts on this GPU, each with its own roofline object:
             # configs[1] = one chain (latency-bound), configs[2] = 256 replicas over 8 GPUs = 32/GPU
