@@ -326,10 +326,22 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      over the previous launch's records.  0 = the host (its threads read every
  *                      record, decide, and write a flag byte per replica before the next launch:
  *                      ~50 ns per record and thread, hidden behind the other group's kernel while
- *                      there are about 8 threads per 32768-move launch).  -1 (default) = 1 where a
- *                      host thread would have more than 4096 records per launch to decide, else 0
- *                      (with eight or more threads per 32768 moves the host's decision costs the
- *                      kernel nothing and measures 1-2 % faster).
+ *                      there are about 8 threads per 32768-move launch).  -1 (default) = 1 where
+ *                      a launch can take several steps ("steps_per_launch"), or where a host thread
+ *                      would have more than 4096 records per launch to decide; else 0.
+ *   "steps_per_launch" where the move kernel decides (above) and the caller asks for energies and
+ *                      counts only (mmc_batch_run; not _run_chains, not the "trace_steps" hook), ONE
+ *                      launch takes every replica of a group through this many consecutive steps
+ *                      -- the same wave commits, evaluates and decides step after step, what one
+ *                      step wrote and read is in the caches for the next -- and sends one record
+ *                      per replica and launch: the sum of dU over its accepted steps and bit masks
+ *                      (accepted, overlap, kind of move).  1, 2, 4, 8 or 16; 0 (default) = 8.  Same
+ *                      chains bit for bit (counts, coordinates, S(k)); the running energies differ
+ *                      from one step per launch by the order of a sum.  mmc_run_stats.launches
+ *                      counts the launches.  1.47e8 against 1.32e8 moves/s (61440 chains of 750
+ *                      molecules).  Launches this long (1.7 ms) want groups whose size is a multiple
+ *                      of 5 * 4 * (compute units) replicas -- 5120 on MI355X: every wavefront the
+ *                      kernel keeps resident then takes the same number of replicas.
  *   "image_by_molecule" -1 (default) = the wave kernel takes the minimum image of an atom pair with
  *                      the image of its molecule's centre of mass where that is the reference's
  *                      vector1D bit for bit: moves made on the device (rigid), and

@@ -50,13 +50,20 @@ def test_steps_per_launch_is_read_from_the_counts():
 
 
 def test_binding_block_names_the_larger_fraction_and_stays_below_one():
-    r = bench.roofline_object(fake(2), 65536, ARGS, {"groups": 2}, 750, 30.0, 1)
+    import glob
+    import json
+    shape = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    mpl = int(json.load(open(shape[-1]))["moves_per_launch"]) if shape else 32768   # the committed launch shape
+    R = 61440 if mpl % 30720 == 0 else 65536
+    st = {"launches": 40, "moves": mpl * 40, "timed_launches": 8, "kernel_ms": 0.35 * 8 * mpl / 32768}
+    r = bench.roofline_object({"st": st, "elapsed": 40 * 250e-6 * mpl / 32768, "streams": 2}, R, ARGS,
+                              {"groups": 2}, 750, 30.0, 1)
     b = r.get("binding")
     if b is None:
         pytest.skip("no committed PMC summary for this launch shape under profiles/")
     v, h = b["fp64_valu_issue"], b["hbm"]
     assert v["peak"] == pytest.approx(1024 * v["clock_ghz"] / 4.0)
-    assert v["achieved"] == pytest.approx(v["valu_insts_per_move"] * 32768 / (r["avg_launch_us"] * 1e-6) / 1e9)
+    assert v["achieved"] == pytest.approx(v["valu_insts_per_move"] * mpl / (r["avg_launch_us"] * 1e-6) / 1e9)
     assert 0 < v["frac"] <= 1.0 and 0 < h["frac"] <= 1.0
     cands = {"fp64_valu_issue": v["frac"]}
     if "access_pattern" in b:   # the kernel's loads and stores without arithmetic: their time / the launch's
