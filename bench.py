@@ -836,6 +836,26 @@ def main():
                     "energy_drift_rel": r_["drift"],
                     "note": "every launch alone on the GPU: its HIP-event duration is its cost and is what "
                             "rocprofv3 --kernel-trace reports for `--streams 1` (profiles/)"}
+            if args.accept != "host" and st.get("device_decisions"):
+                # The same chains with the accept decision on the HOST (north_star's placement: its
+                # threads read a record per replica and step, decide, and send a flag byte back),
+                # one step per launch: same seeds, the same decisions bit for bit.
+                ah = argparse.Namespace(**{**vars(args), "accept": "host"})
+                shh = dict(shape, steps=min(max(shape["steps"], 100), 200), warmup=min(shape["warmup"], 24),
+                           prewarm=104)
+                rh = measure_moves(R, a, ah, local_rank, g0, barrier, shh)
+                rfh = roofline_object(rh, R, ah, shh, n_mol, box, parts_used)
+                out["host_decides"] = {
+                    "value": rh["st"]["moves"] / rh["elapsed"], "unit": "moves/s",
+                    "ms_per_step": 1e3 * rh["elapsed"] / shh["steps"], "steps": shh["steps"],
+                    "avg_launch_us": rfh["avg_launch_us"] if rfh else None,
+                    "moves_per_launch": rfh["moves_per_launch"] if rfh else None,
+                    "acceptance": (rh["st"]["trans_accept"] + rh["st"]["rot_accept"]) / max(rh["st"]["moves"], 1),
+                    "energy_drift_rel": rh["drift"],
+                    "note": "`--accept host`: the sequential accept/reject on the host's threads, one launch "
+                            "and one 64-byte record per replica per step; the headline lets the move kernel "
+                            "take the same decision (same Philox uniform, same arithmetic) and eight steps "
+                            "per launch"}
             out["full_energy_eval"]["single_system_latency"] = single_system_latency(a, local_rank)
             out["call_surface"] = call_surface(a)
         if not args.no_cpu and world == 1:         # the CPU baseline leg: rank 0 at N=1 only
