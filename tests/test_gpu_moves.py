@@ -235,3 +235,33 @@ def test_rigid_generator_draw_by_draw():
                 assert np.abs(coords[:3] - (c0 + (x0 - c0) @ Rm.T)).max() < 2e-13
                 n_r += 1
         assert n_t > 40 and n_r > 40
+
+
+@pytest.mark.parametrize("per_launch", [1, 8])
+def test_quaternion_mode_with_the_kernel_s_own_decisions(per_launch):
+    """The reference's quaternion route with the accept decision in the move kernel and several steps
+    per launch: the same chains as with the host's decision -- energies, counts, coordinates AND
+    the committed orientations (totProps.quat, main.jl:619)."""
+    n_mol, R = 216, 8
+    a, quat, db = quaternion_system(n_mol, True, seed=8)
+    out = []
+    for on_device in (0, 1):
+        with make_batch(a, R, 7.5) as b:
+            b.set_orientations(quat, db, faithful=True)
+            b.set_option("device_moves", 1)
+            b.set_option("kernel", 2)
+            b.set_option("persistent", 0)
+            b.set_option("accept_on_device", on_device)
+            b.set_option("steps_per_launch", per_launch)
+            e0 = b.potential_ewald(as_array=True)["energy"].copy()
+            e1, st = b.run(2 * n_mol + 3, 298.15, 0.3, 0.1, seed=1, energies=e0, n_groups=2, n_parts=1,
+                           n_threads=2)
+            assert st["device_decisions"] == (st["moves"] if on_device else 0)
+            t1 = b.potential_ewald(as_array=True)["energy"]
+            assert np.abs(e1 - t1).max() < 1e-9 * np.abs(t1).max()
+            out.append((e1.copy(), [st[k] for k in ("trans_accept", "rot_accept", "overlaps")],
+                        b.get_orientations(R - 1), b.get_replica(R - 1)[:2]))
+    assert out[0][1] == out[1][1] and out[0][1][0] > 0 and out[0][1][1] > 0
+    assert np.array_equal(out[0][2], out[1][2])
+    assert all(np.array_equal(x, y) for x, y in zip(out[0][3], out[1][3]))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-12 * np.abs(out[0][0]).max()
