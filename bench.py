@@ -750,6 +750,7 @@ def main():
             "acceptance": red["accepted"] / max(total_moves, 1),
             "overlaps": int(red["overlaps"]),
             "torn_result_records": int(st["torn_records"]),
+            "driver_wall_ms": st["wall_ms"],   # the native driver's own clock over the timed call (this rank)
             "energy_mean_per_replica": red["energy_sum"] / (R * world),
             "energy_drift_rel": drift_max,
             "ns_per_full_energy_eval": 1e9 * t_full_max / R,

@@ -379,6 +379,9 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #define WV_DECIDE(o0, o1) decide_here(o0, o1)
 #define WV_RECORD_OVL(o) (n_sub > 1 ? false : (o))
 #define WV_STORE_IF (sub + 1 == n_sub)
+// (a launch of several steps is long -- 1.7 ms -- and the driver times the next group's launch by this
+// launch's records: they must reach the host as the units end, not with the kernel's last write-back)
+#define WV_STORE_SYSTEM MULTI
 #define WV_ZERO opaque_f64(0.0)
 #define WV_SUBST SUBST
 #define WV_IMG IMG
@@ -404,6 +407,7 @@ __global__ __launch_bounds__(WV_MWAVES * 64) __attribute__((amdgpu_waves_per_eu(
 #undef WV_DECIDE
 #undef WV_RECORD_OVL
 #undef WV_STORE_IF
+#undef WV_STORE_SYSTEM
         if (n_sub > 1) // what this step stored (S_new, soon the commit) is read by the next
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } // sub
