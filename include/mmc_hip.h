@@ -338,8 +338,8 @@ int32_t mmc_batch_set_parts(mmc_batch *b, int32_t n_parts);
  *                      (accepted, overlap, kind of move).  1, 2, 4, 8 or 16; 0 (default) = 8.  Same
  *                      chains bit for bit (counts, coordinates, S(k)); the running energies differ
  *                      from one step per launch by the order of a sum.  mmc_run_stats.launches
- *                      counts the launches.  1.47e8 against 1.32e8 moves/s (61440 chains of 750
- *                      molecules).  Launches this long (1.7 ms) want groups whose size is a multiple
+ *                      counts the launches.  1.43e8 against 1.31e8 moves/s (61440 chains of 750
+ *                      molecules, one run of bench.py).  Launches this long (1.7 ms) want groups whose size is a multiple
  *                      of 5 * 4 * (compute units) replicas -- 5120 on MI355X: every wavefront the
  *                      kernel keeps resident then takes the same number of replicas.
  *   "image_by_molecule" -1 (default) = the wave kernel takes the minimum image of an atom pair with
