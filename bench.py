@@ -320,7 +320,10 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         return None
     bytes_move = algorithmic_bytes_per_move(n_mol, box)
     moves_per_launch = st["moves"] / max(st["launches"], 1)
-    steps_per_launch = max(1, int(round(moves_per_launch * shape["groups"] / max(R, 1))))
+    units_per_launch = max(R, 1) / max(shape["groups"], 1)            # replicas a launch takes
+    avg_steps = moves_per_launch / units_per_launch                   # e.g. 6.67 for launches of 8 + 8 + 4 steps
+    steps_per_launch = next((k for k in (1, 2, 4, 8, 16) if k >= avg_steps - 1e-9), 16)   # the launches' nominal length
+    profile_shape = units_per_launch * steps_per_launch               # the launch the committed counters belong to
     overlapped = res.get("streams", 1) > 1 and shape["groups"] > 1
     span = (st["kernel_ms"] * 1e-3 / st["timed_launches"]) if st["timed_launches"] else None
     if overlapped or span is None:
@@ -332,8 +335,12 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         t_source = "HIP events around single launches (every Nth) on the kernel's stream"
     achieved = bytes_move * moves_per_launch / t_launch / 1e9
     name = kernel_name(args.kernel, moves_per_launch, parts_used)
-    traffic, source = pmc_traffic(name, moves_per_launch)
-    ex = pmc_extras(name, moves_per_launch)
+    # (the committed counters are per launch of the nominal length: per move they hold for a call
+    # whose last launch is shorter, too)
+    traffic, source = pmc_traffic(name, profile_shape)
+    if traffic:
+        traffic *= moves_per_launch / profile_shape
+    ex = pmc_extras(name, profile_shape)
     out = {
         "kernel": name, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": source,
@@ -368,8 +375,9 @@ def roofline_object(res, R, args, shape, n_mol, box, parts_used):
         # what the kernel's own loads and stores take with the arithmetic removed: the time of that
         # replay over the time of the launch (<= 1: how close the kernel is to being nothing but its
         # memory accesses)
-        pat = access_pattern_floor(moves_per_launch / max(steps_per_launch, 1), steps_per_launch)
+        pat = access_pattern_floor(units_per_launch, steps_per_launch)
         if pat:
+            pat = (pat[0] * avg_steps / steps_per_launch, pat[1], pat[2])   # this run's average launch
             pf = pat[0] * 1e-6 / t_launch
             b["access_pattern"] = {"floor_us": pat[0], "frac": pf, "TB_per_s_of_its_bytes_without_arithmetic": pat[1],
                                    "source": pat[2]}

@@ -83,3 +83,20 @@ def test_shapes():
     assert bench.server_lat_parts(1, 750) == 16 and bench.server_lat_parts(1, 10000) == 84
     assert bench.server_lat_parts(512, 750) == 0
     assert bench.kernel_name(3, 32768, 1) == "k_move_eval_wave" and bench.kernel_name(3, 32, 5) == "k_move_eval_fast"
+
+
+def test_a_call_whose_last_launch_is_shorter_still_gets_its_binding_block():
+    """The driver's `--steps 20`: launches of 8 + 8 + 4 steps.  The committed counters belong to the
+    8-step launch; per move they hold for the call's average launch."""
+    import glob
+    import json
+    shape = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not shape or int(json.load(open(shape[-1]))["moves_per_launch"]) != 30720 * 8:
+        pytest.skip("the committed counters are not those of 8-step launches of 30720 replicas")
+    st = {"launches": 6, "moves": 61440 * 20, "timed_launches": 2, "kernel_ms": 4.4}
+    r = bench.roofline_object({"st": st, "elapsed": 0.0090, "streams": 2}, 61440, ARGS, {"groups": 2}, 750, 30.0, 1)
+    assert r["steps_per_launch"] == 8 and r["moves_per_launch"] == pytest.approx(61440 * 20 / 6)
+    b = r["binding"]
+    assert 0 < b["frac"] <= 1.0 and b["bound"] in ("fp64_valu_issue", "hbm_access_pattern")
+    assert b["hbm"]["bytes_per_move"] == pytest.approx(json.load(open(shape[-1]))["bytes_per_move"])
+    assert b["access_pattern"]["floor_us"] == pytest.approx(b["access_pattern"]["frac"] * r["avg_launch_us"])
