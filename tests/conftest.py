@@ -42,7 +42,14 @@ def pytest_configure(config):
             f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node 2 "
             f"--master-addr 127.0.0.1 --master-port 29543 bench.py --gpus 2 --replicas 32 "
             f"--steps 200 --warmup 20 --no-cpu --no-secondary --threads 2 "
-            f"> {out}/two32.json 2> {out}/two32.err; echo $? > {out}/two32.rc")
+            f"> {out}/two32.json 2> {out}/two32.err; echo $? > {out}/two32.rc; "
+            # the headline's own mode under two ranks: the move kernel decides, eight steps per launch
+            f"{sys.executable} -m torch.distributed.run --nnodes=1 --nproc-per-node 2 "
+            f"--master-addr 127.0.0.1 --master-port 29545 bench.py --gpus 2 --replicas 10240 "
+            f"--steps 24 --warmup 8 --no-cpu --no-secondary --threads 2 "
+            f"> {out}/two_dev.json 2> {out}/two_dev.err; echo $? > {out}/two_dev.rc; "
+            f"{sys.executable} bench.py --gpus 1 --replicas 20480 --steps 24 --warmup 8 --no-cpu "
+            f"--no-secondary --threads 2 > {out}/one_dev.json 2> {out}/one_dev.err; echo $? > {out}/one_dev.rc")
         proc = subprocess.Popen(["bash", "-c", script], env=env)
         config._mmc_dist = (proc, out)
 

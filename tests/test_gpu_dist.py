@@ -60,6 +60,22 @@ def test_two_ranks_of_32_chains_run_the_move_server(dist_rehearsal):
     assert 0.5 < d["acceptance"] < 0.95
 
 
+def test_two_ranks_in_the_headline_s_mode_run_the_same_chains_as_one(dist_rehearsal):
+    """The mode the headline runs in -- the move kernel takes the accept decision, a launch takes a
+    group through eight steps -- under two ranks of 10240 chains, against one process running global
+    indices 0..20479: the same chains (accept count, energy sum), whatever the split."""
+    two, one = load(dist_rehearsal, "two_dev"), load(dist_rehearsal, "one_dev")
+    for d in (two, one):
+        assert d["config"]["accept_decision"] == "move kernel" and d["roofline"]["steps_per_launch"] == 8
+        assert d["roofline"]["kernel"] == "k_move_eval_wave"
+        assert d["energy_drift_rel"] < 1e-12 and d["torn_result_records"] == 0
+        assert d["config"]["replicas_total"] == 20480 and d["steps"] == 24
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["acceptance"] == one["acceptance"] and two["overlaps"] == one["overlaps"]
+    e2, e1 = two["energy_mean_per_replica"], one["energy_mean_per_replica"]
+    assert abs(e2 - e1) < 1e-13 * abs(e1), (e2, e1)
+
+
 def test_rccl_collective_behind_the_c_abi():
     """mmc_dist_*: the final reduction for hosts without torch.  A one-GPU box can form a
     communicator of ONE rank only (RCCL wants a GPU per rank): that still goes through
