@@ -725,6 +725,56 @@ def test_driver_device_moves_stepped_by_the_oracle(kernel, R, parts, on_device, 
     assert n_rej > 5 and n_rot > 10          # rejected moves and rotations were among the checked
 
 
+@pytest.mark.parametrize("per_launch,n_steps", [(8, 90), (16, 41)])
+def test_several_steps_per_launch_stepped_by_the_oracle(per_launch, n_steps, orc):
+    """The headline's mode against the ORACLE: the move kernel decides and one launch takes a replica
+    through several steps; no record of single steps comes back, so the oracle steps the same chains
+    on its own -- proposals rebuilt from the Philox draws, dU from orc.trial_move, Metropolis
+    (auxillary.jl:106-114) with math.exp and the step's uniform -- and the batch must end where the
+    oracle does: accept counts, the sum of the accepted dU, coordinates, S(k)."""
+    import math
+    a = common.nist_arrays(4, "unwrapped")
+    n_mol, box = a["com"].shape[0], a["box"]
+    R, seed, T, dr, dphi = 24, 777, 298.15, 0.316555789, 0.05
+    check = (0, 11, R - 1)
+    with make_batch(a, R) as b:
+        b.set_option("kernel", 2)
+        b.set_option("device_moves", 1)
+        b.set_option("persistent", 0)
+        b.set_option("accept_on_device", 1)
+        b.set_option("steps_per_launch", per_launch)
+        e0 = b.potential_ewald(as_array=True)["energy"].copy()
+        e1, st = b.run(n_steps, T, dr, dphi, seed=seed, energies=e0, n_groups=2, n_parts=1, n_threads=2,
+                       replica0=3)
+        assert st["device_decisions"] == R * n_steps and st["launches"] == 2 * -(-n_steps // per_launch)
+        final = {r: b.get_replica(r) for r in check}
+    for r in check:
+        s = common.oracle_system(a)
+        ew = orc.Ewald(5.6 / box, 5, 27, box)
+        orc.recip_long(ew, s.coords, s.charge, box)
+        running, n_acc = 0.0, 0
+        for step in range(n_steps):
+            i = step % n_mol
+            kind, c_new, a_new, u = _rigid_proposal(seed, 3 + r, step, s.com[i].copy(),
+                                                    s.coords[3 * i:3 * i + 3].copy(), box, dr, dphi)
+            d, ov = orc.trial_move(i + 1, s, ew, RCUT, RCUT, c_new, a_new)
+            delta = d[0] + d[1] + d[2]
+            x = delta / T
+            if (x < 0.0 or math.exp(-x) > u) and not ov:
+                running += delta
+                n_acc += 1
+                s.com[i] = c_new
+                s.coords[3 * i:3 * i + 3] = a_new
+                ew.sumQExpOld = ew.sumQExpNew.copy()
+            else:
+                ew.sumQExpNew = ew.sumQExpOld.copy()
+        com, coords, S = final[r]
+        assert np.abs(com - s.com).max() < 2e-13 and np.abs(coords - s.coords).max() < 2e-13, r
+        assert np.abs(S - ew.sumQExpOld).max() < 1e-11 * np.abs(ew.sumQExpOld).max(), r
+        assert abs((e1[r] - e0[r]) - running) < TOL * 1e5, r
+        assert 0 < n_acc < n_steps
+
+
 @pytest.mark.parametrize("cfg,parts", [(4, 1), (4, 3), (1, 1)])
 def test_minimum_image_by_molecule_is_bit_identical(cfg, parts):
     """Option "image_by_molecule": where gate + 2 r_mol < box / 2 (NIST configuration 4: 750 molecules
